@@ -1,0 +1,273 @@
+// Host-side spectral decomposition (see crab_eigen.h) and the worker pool that runs one
+// decomposition per site class / per branch in parallel.
+#include "crab_eigen.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace crab {
+
+// ---------------------------------------------------------------------------------------------
+// Householder reduction to tridiagonal form followed by QL with implicit shifts.
+// a is n x n row-major; on exit column k of a is the eigenvector of d[k].
+// ---------------------------------------------------------------------------------------------
+static void tridiagonalise(int n, double *a, double *d, double *e)
+{
+    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
+    for (int i = n - 1; i > 0; --i) {
+        const int l = i - 1;
+        double h = 0.0;
+        if (l > 0) {
+            double scale = 0.0;
+            for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+            if (scale == 0.0) {
+                e[i] = A(i, l);
+            } else {
+                for (int k = 0; k <= l; ++k) {
+                    A(i, k) /= scale;
+                    h += A(i, k) * A(i, k);
+                }
+                double f = A(i, l);
+                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                A(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    A(j, i) = A(i, j) / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+                    e[j] = g / h;
+                    f += e[j] * A(i, j);
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = A(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) A(j, k) -= f * e[k] + g * A(i, k);
+                }
+            }
+        } else {
+            e[i] = A(i, l);
+        }
+        d[i] = h;
+    }
+    d[0] = 0.0;
+    e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if (d[i] != 0.0) {
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+                for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+            }
+        }
+        d[i] = A(i, i);
+        A(i, i) = 1.0;
+        for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+    }
+}
+
+static bool ql_implicit(int n, double *d, double *e, double *z)
+{
+    auto Z = [&](int i, int j) -> double & { return z[(size_t)i * n + j]; };
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= eps * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 120) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    e[i + 1] = r = std::hypot(f, g);
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    for (int k = 0; k < n; ++k) {
+                        f = Z(k, i + 1);
+                        Z(k, i + 1) = s * Z(k, i) + c * f;
+                        Z(k, i) = c * Z(k, i) - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
+}
+
+bool symmetric_eigen(int n, double *a, double *d)
+{
+    std::vector<double> e(n);
+    for (int i = 0; i < n; ++i)  // symmetrise from the lower triangle
+        for (int j = i + 1; j < n; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i];
+    tridiagonalise(n, a, d, e.data());
+    return ql_implicit(n, d, e.data(), a);
+}
+
+bool spectral_decompose_plain(int n, const double *Q, const double *pi, double *U, double *lam, double *Uinv)
+{
+    std::vector<double> S((size_t)n * n), sq(n), isq(n);
+    for (int i = 0; i < n; ++i) {
+        if (!(pi[i] > 0.0)) return false;
+        sq[i] = std::sqrt(pi[i]);
+        isq[i] = 1.0 / sq[i];
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = sq[i] * Q[(size_t)i * n + j] * isq[j];
+    if (!symmetric_eigen(n, S.data(), lam)) return false;
+    for (int k = 0; k < n; ++k)
+        if (!std::isfinite(lam[k])) return false;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k) {
+            const double v = S[(size_t)i * n + k];
+            U[(size_t)i * n + k] = isq[i] * v;
+            Uinv[(size_t)k * n + i] = v * sq[i];
+        }
+    return true;
+}
+
+bool spectral_decompose(int n, const double *Q, const double *pi, double *out)
+{
+    std::vector<double> U((size_t)n * n), Ui((size_t)n * n), lam(n);
+    if (!spectral_decompose_plain(n, Q, pi, U.data(), lam.data(), Ui.data())) return false;
+    std::memset(out, 0, sizeof(double) * EIG_STRIDE);
+    for (int k = 0; k < n; ++k) {
+        for (int i = 0; i < n; ++i) {
+            out[EIG_UT + k * NS + i] = U[(size_t)i * n + k];
+            out[EIG_UINV + k * NS + i] = Ui[(size_t)k * n + i];
+        }
+        out[EIG_LAM + k] = lam[k];
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// worker pool
+// ---------------------------------------------------------------------------------------------
+namespace {
+class Pool {
+  public:
+    Pool()
+    {
+        int want = 0;
+        if (const char *s = std::getenv("CRAB_HOST_THREADS")) want = std::atoi(s);
+        if (want <= 0) {
+            unsigned hc = std::thread::hardware_concurrency();
+            want = (int)std::min<unsigned>(hc ? hc : 1u, 16u);
+        }
+        n_threads_ = std::max(1, want);
+        for (int t = 1; t < n_threads_; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    int size() const { return n_threads_; }
+
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (n == 1 || n_threads_ == 1) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(run_m_);  // one parallel_for at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            pending_ = n;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    void loop()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+                if (!fn_) continue;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0, n_threads_ = 1;
+    unsigned long epoch_ = 0;
+    bool stop_ = false;
+};
+
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+}  // namespace
+
+void parallel_for(int n, const std::function<void(int)> &fn) { pool().run(n, fn); }
+int host_threads() { return pool().size(); }
+
+}  // namespace crab

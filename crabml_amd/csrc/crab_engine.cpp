@@ -1,0 +1,1140 @@
+// Host side of libcrabml_amd.so: the C ABI declared in include/crabml_amd.h.
+//
+// What lives here is what rust/src/lib.rs + the orchestration parts of rust/src/likelihood.rs and
+// rust/src/branch_site_likelihood.rs do on the host in the reference: argument validation, tree
+// construction, choosing an eigensystem and an effective time for every (branch, class), and the
+// final reduction -- re-thought for a device that keeps the tree program and the alignment resident:
+//   * the tree is compiled once into a flat post-order "program" (TreeOp list) with Sethi-Ullman child
+//     ordering so the register/stack footprint of the on-chip tree walk is minimal;
+//   * the alignment is compressed into weighted site patterns once and stored as one byte per code;
+//   * per evaluation only the packed eigensystems (K x 66 KB) and a few small tables cross PCIe.
+#include "../../include/crabml_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "crab_eigen.h"
+#include "crab_kernels.h"
+
+using namespace crab;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct HipError {
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _err = (expr);                                                                         \
+        if (_err != hipSuccess) {                                                                         \
+            throw HipError{std::string(#expr) + ": " + hipGetErrorString(_err)};                          \
+        }                                                                                                 \
+    } while (0)
+
+struct ArgError {
+    int code;
+    std::string msg;
+};
+
+// growable device allocation; contents are not preserved across growth
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8;
+        HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// growable pinned host staging buffer
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8;
+        HIP_CHECK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+double now_ms()
+{
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// The tree compiled for the device: topology tables plus the flat post-order op list.
+struct TreeProgram {
+    int n_nodes = 0, root = -1, n_leaf_rows = 0;
+    std::vector<int> parent, child_start, child, leaf_row;
+    std::vector<char> in_leaf_set, reachable;
+    std::vector<TreeOp> ops;
+    int max_depth = 0, first_gemm_node = -1;
+    int64_t n_gemm_edges = 0, n_leaf_edges = 0;
+};
+
+struct crab_engine : TreeProgram {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+    std::string err;
+
+    // ---- tree ----
+    bool have_tree = false;
+    bool ops_uploaded = false;
+
+    // ---- alignment ----
+    bool have_aln = false;
+    int n_states = 0, aln_rows = 0;
+    int64_t n_sites = 0, n_pat_total = 0, pat_begin = 0, pat_end = 0, n_pat = 0, n_pat_pad = 0;
+    std::vector<int64_t> site_to_pat;  // global pattern id per site
+    std::vector<double> weights;       // per local pattern
+
+    // ---- device state ----
+    DevBuf<TreeOp> d_ops;
+    DevBuf<uint8_t> d_codes;
+    DevBuf<double> d_weights, d_eig, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
+    DevBuf<int32_t> d_eig_id, d_pidx, d_stack_e, d_e;
+    PinBuf<double> h_eig, h_small, h_out;
+    PinBuf<int32_t> h_int;
+
+    // ---- last-eval facts ----
+    double last_device_ms = 0, last_prune_ms = 0, last_eigen_ms = 0;
+    int64_t last_dense = 0, last_gather = 0;
+
+    ~crab_engine()
+    {
+        (void)hipSetDevice(device);
+        d_ops.release(); d_codes.release(); d_weights.release(); d_eig.release(); d_teff.release(); d_P.release();
+        d_pi.release(); d_props.release(); d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
+        d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_pidx.release(); d_stack_e.release(); d_e.release();
+        h_eig.release(); h_small.release(); h_out.release(); h_int.release();
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (ev_k0) (void)hipEventDestroy(ev_k0);
+        if (ev_k1) (void)hipEventDestroy(ev_k1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: run a body, translate exceptions into status codes
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+int guarded(crab_engine *e, F &&body)
+{
+    try {
+        body();
+        return CRAB_OK;
+    } catch (const ArgError &a) {
+        (e ? e->err : g_last_error) = a.msg;
+        return a.code;
+    } catch (const HipError &h) {
+        (e ? e->err : g_last_error) = h.msg;
+        return CRAB_ERR_DEVICE;
+    } catch (const std::bad_alloc &) {
+        (e ? e->err : g_last_error) = "host allocation failed";
+        return CRAB_ERR_DEVICE;
+    } catch (const std::exception &x) {
+        (e ? e->err : g_last_error) = x.what();
+        return CRAB_ERR_ARG;
+    }
+}
+
+[[noreturn]] void fail(int code, const std::string &msg) { throw ArgError{code, msg}; }
+
+// ---------------------------------------------------------------------------------------------
+// tree -> program
+// ---------------------------------------------------------------------------------------------
+void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_ids,
+                int n_leaves)
+{
+    if (n_nodes < 1 || !parents || (n_leaves > 0 && !leaf_ids) || n_leaves < 0) fail(CRAB_ERR_ARG, "crab_set_tree: bad arguments");
+    e->n_nodes = n_nodes;
+    e->parent.assign(n_nodes, -1);
+    std::vector<char> seen(n_nodes, 0);
+    for (int k = 0; k < n_nodes; ++k) {
+        const int v = node_ids ? node_ids[k] : k;
+        if (v < 0 || v >= n_nodes) fail(CRAB_ERR_ARG, "tree_structure: node id " + std::to_string(v) + " out of range");
+        if (parents[k] >= n_nodes) fail(CRAB_ERR_ARG, "tree_structure: parent id " + std::to_string(parents[k]) + " out of range");
+        e->parent[v] = parents[k] < 0 ? -1 : parents[k];
+        seen[v] = 1;
+    }
+    // children in order of appearance (likelihood.rs:49-54)
+    e->child_start.assign(n_nodes + 1, 0);
+    for (int k = 0; k < n_nodes; ++k)
+        if (parents[k] >= 0) e->child_start[parents[k] + 1]++;
+    for (int v = 0; v < n_nodes; ++v) e->child_start[v + 1] += e->child_start[v];
+    e->child.assign(std::max(1, e->child_start[n_nodes]), -1);
+    {
+        std::vector<int> fill(n_nodes, 0);
+        for (int k = 0; k < n_nodes; ++k)
+            if (parents[k] >= 0) e->child[e->child_start[parents[k]] + fill[parents[k]]++] = node_ids ? node_ids[k] : k;
+    }
+    e->root = -1;
+    for (int v = 0; v < n_nodes; ++v)
+        if (e->parent[v] < 0) {
+            e->root = v;
+            break;
+        }
+    if (e->root < 0) fail(CRAB_ERR_NO_ROOT, "No root node found");
+    e->in_leaf_set.assign(n_nodes, 0);
+    e->leaf_row.assign(n_nodes, -1);
+    e->n_leaf_rows = n_leaves;
+    for (int r = 0; r < n_leaves; ++r) {
+        const int v = leaf_ids[r];
+        if (v < 0 || v >= n_nodes) fail(CRAB_ERR_ARG, "leaf_node_ids: node id " + std::to_string(v) + " out of range");
+        e->in_leaf_set[v] = 1;
+        e->leaf_row[v] = r;
+    }
+    if (e->in_leaf_set[e->root]) fail(CRAB_ERR_ARG, "the root node is listed as a leaf: nothing to prune");
+
+    // ---- pass 1: iterative post-order over nodes reachable from the root; cycle guard ----
+    std::vector<int> order;
+    order.reserve(n_nodes);
+    e->reachable.assign(n_nodes, 0);
+    {
+        std::vector<std::pair<int, int>> st;
+        st.emplace_back(e->root, 0);
+        e->reachable[e->root] = 1;
+        while (!st.empty()) {
+            auto &[v, k] = st.back();
+            const bool expand = !e->in_leaf_set[v];
+            if (expand && e->child_start[v] + k < e->child_start[v + 1]) {
+                const int c = e->child[e->child_start[v] + k];
+                ++k;
+                if (e->reachable[c]) fail(CRAB_ERR_ARG, "tree_structure contains a cycle or a repeated node");
+                e->reachable[c] = 1;
+                st.emplace_back(c, 0);
+            } else {
+                order.push_back(v);
+                st.pop_back();
+            }
+        }
+    }
+    // ---- pass 2: stack need per internal node (Sethi-Ullman) ----
+    auto is_internal = [&](int v) { return !e->in_leaf_set[v]; };
+    std::vector<int> need(n_nodes, 0);
+    std::vector<std::vector<int>> int_children(n_nodes);
+    for (int v : order) {
+        if (!is_internal(v)) continue;
+        auto &ic = int_children[v];
+        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci) {
+            const int c = e->child[ci];
+            if (is_internal(c)) ic.push_back(c);
+        }
+        std::stable_sort(ic.begin(), ic.end(), [&](int x, int y) { return need[x] > need[y]; });
+        int nd = 0;
+        for (size_t i = 0; i < ic.size(); ++i) nd = std::max(nd, need[ic[i]] + (i > 0 ? 1 : 0));
+        need[v] = nd;
+    }
+    e->max_depth = need[e->root];
+
+    // ---- pass 3: emit ops, iteratively ----
+    e->ops.clear();
+    e->n_gemm_edges = e->n_leaf_edges = 0;
+    struct Frame {
+        int v, depth;
+        size_t next_child;  // index into int_children[v]
+        bool any_term;
+        int n_terms;        // terms multiplied into this node so far (a rescale is forced every 4th)
+    };
+    auto emit = [&](int kind, int node, int flags, int arg, int slot) {
+        TreeOp op{};
+        op.kind = kind;
+        op.node = node;
+        op.flags = flags;
+        op.arg = arg;
+        op.slot = slot;
+        e->ops.push_back(op);
+    };
+    std::vector<Frame> fs;
+    fs.push_back({e->root, 0, 0, false, 0});
+    while (!fs.empty()) {
+        Frame &f = fs.back();
+        const auto &ic = int_children[f.v];
+        if (f.next_child < ic.size()) {
+            const size_t i = f.next_child++;
+            if (i > 0) e->ops.back().flags |= F_PUSH, e->ops.back().slot = f.depth;  // save the running product
+            fs.push_back({ic[i], f.depth + (i > 0 ? 1 : 0), 0, false, 0});
+            continue;
+        }
+        // all internal-child subtrees of f.v have been emitted *except* that each child's GEMM must follow its
+        // subtree immediately; that is done when the child frame is popped (below).  Here: leaf children, FIN.
+        const int v = f.v;
+        bool any = f.any_term;
+        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci) {
+            const int c = e->child[ci];
+            if (is_internal(c)) continue;
+            int flags = any ? F_MUL_PROD : 0;
+            if (++f.n_terms % 4 == 0) flags |= F_RESCALE;
+            emit(OP_LEAF, c, flags, e->leaf_row[c], 0);
+            e->n_leaf_edges++;
+            any = true;
+        }
+        if (!any) emit(OP_CONST, v, 0, 1, 0);  // childless non-leaf node: all ones (likelihood.rs:178)
+        e->ops.back().flags |= F_FIN;
+        const int depth = f.depth;
+        fs.pop_back();
+        if (!fs.empty()) {
+            // v is an internal child of the frame below: cross its branch now
+            Frame &p = fs.back();
+            const bool first = !p.any_term;
+            int flags = 0, slot = 0;
+            if (!first) {
+                flags |= F_POP_MUL;
+                slot = p.depth;
+            }
+            (void)depth;
+            if (++p.n_terms % 4 == 0) flags |= F_RESCALE;
+            emit(OP_GEMM, v, flags, -1, slot);
+            e->n_gemm_edges++;
+            p.any_term = true;
+        }
+    }
+    // prefetch chain: each GEMM op names the node of the next one
+    int next_gemm = -1;
+    for (int i = (int)e->ops.size() - 1; i >= 0; --i)
+        if (e->ops[i].kind == OP_GEMM) {
+            e->ops[i].arg = next_gemm;
+            next_gemm = e->ops[i].node;
+        }
+    e->first_gemm_node = next_gemm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// alignment -> compressed, sliced, byte-coded patterns on the device
+// ---------------------------------------------------------------------------------------------
+uint64_t mix64(uint64_t h, uint64_t v)
+{
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    return h;
+}
+
+// Collapses identical alignment columns.  cols: column-major byte image [n_sites][n_leaves] (output),
+// site_to_pat[s] = pattern id, first_site[p] = first site showing pattern p, count[p] = multiplicity.
+// Pattern ids follow first appearance, so the pattern order (and every sum over it) is deterministic.
+void compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
+                       std::vector<uint8_t> &cols, std::vector<int64_t> &site_to_pat, std::vector<int64_t> &first_site,
+                       std::vector<double> &count)
+{
+    // column-major byte image with missing data canonicalised to n_states
+    cols.assign((size_t)n_sites * n_leaves, 0);
+    for (int r = 0; r < n_leaves; ++r) {
+        const int32_t *row = codes + (size_t)r * n_sites;
+        for (int64_t s = 0; s < n_sites; ++s) {
+            const int32_t c = row[s];
+            cols[(size_t)s * n_leaves + r] = (c >= 0 && c < n_states) ? (uint8_t)c : (uint8_t)n_states;
+        }
+    }
+    site_to_pat.assign(n_sites, 0);
+    first_site.clear();
+    count.clear();
+    if (compress) {
+        std::unordered_map<uint64_t, std::vector<int64_t>> table;
+        table.reserve((size_t)n_sites * 2);
+        for (int64_t s = 0; s < n_sites; ++s) {
+            const uint8_t *col = &cols[(size_t)s * n_leaves];
+            uint64_t h = 0x2545f4914f6cdd1dull;
+            int r = 0;
+            for (; r + 8 <= n_leaves; r += 8) {
+                uint64_t w;
+                std::memcpy(&w, col + r, 8);
+                h = mix64(h, w);
+            }
+            for (; r < n_leaves; ++r) h = mix64(h, col[r]);
+            auto &bucket = table[h];
+            int64_t found = -1;
+            for (int64_t pid : bucket)
+                if (std::memcmp(&cols[(size_t)first_site[pid] * n_leaves], col, n_leaves) == 0) {
+                    found = pid;
+                    break;
+                }
+            if (found < 0) {
+                found = (int64_t)first_site.size();
+                first_site.push_back(s);
+                count.push_back(0.0);
+                bucket.push_back(found);
+            }
+            count[found] += 1.0;
+            site_to_pat[s] = found;
+        }
+    } else {
+        first_site.resize(n_sites);
+        count.assign(n_sites, 1.0);
+        for (int64_t s = 0; s < n_sites; ++s) first_site[s] = site_to_pat[s] = s;
+    }
+}
+
+void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
+                    int64_t pat_begin, int64_t pat_end)
+{
+    if (!codes || n_leaves < 1 || n_sites < 0) fail(CRAB_ERR_ARG, "crab_set_alignment: bad arguments");
+    if (n_states < 1 || n_states > NS - 1) fail(CRAB_ERR_ARG, "n_states must be in [1, 63], got " + std::to_string(n_states));
+    e->have_aln = false;
+    e->n_states = n_states;
+    e->aln_rows = n_leaves;
+    e->n_sites = n_sites;
+    std::vector<uint8_t> cols;
+    std::vector<int64_t> first_site;  // representative site per global pattern
+    std::vector<double> count;
+    compress_patterns(codes, n_leaves, n_sites, n_states, compress, cols, e->site_to_pat, first_site, count);
+    e->n_pat_total = (int64_t)first_site.size();
+    if (pat_end < 0 || pat_end > e->n_pat_total) pat_end = e->n_pat_total;
+    if (pat_begin < 0) pat_begin = 0;
+    if (pat_begin > pat_end) pat_begin = pat_end;
+    e->pat_begin = pat_begin;
+    e->pat_end = pat_end;
+    e->n_pat = pat_end - pat_begin;
+    const int tile = prune_tile_width();
+    e->n_pat_pad = ((e->n_pat + tile - 1) / tile) * tile;
+    if (e->n_pat_pad == 0) e->n_pat_pad = tile;
+
+    std::vector<uint8_t> img((size_t)n_leaves * e->n_pat_pad, (uint8_t)n_states);
+    e->weights.assign(e->n_pat_pad, 0.0);
+    for (int64_t p = 0; p < e->n_pat; ++p) {
+        const uint8_t *col = &cols[(size_t)first_site[pat_begin + p] * n_leaves];
+        for (int r = 0; r < n_leaves; ++r) img[(size_t)r * e->n_pat_pad + p] = col[r];
+        e->weights[p] = count[pat_begin + p];
+    }
+    HIP_CHECK(hipSetDevice(e->device));
+    e->d_codes.ensure(img.size());
+    e->d_weights.ensure(e->n_pat_pad);
+    HIP_CHECK(hipMemcpyAsync(e->d_codes.p, img.data(), img.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_weights.p, e->weights.data(), e->n_pat_pad * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->have_aln = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one evaluation
+// ---------------------------------------------------------------------------------------------
+struct EvalPlan {
+    int n_eig = 0;                      // eigensystems to decompose
+    const double *Q = nullptr;          // [n_eig][n][n]
+    int M = 0;                          // transition matrices to build
+    std::vector<int32_t> eig_id;        // [M]
+    std::vector<double> t_eff;          // [M]
+    int K = 0;                          // classes walked by the pruning kernel
+    std::vector<int32_t> pidx;          // [K][n_nodes]
+    std::vector<double> props;          // [K]
+    int mix_mode = MIX_LOGSUMEXP_CLAMP;
+    bool by_class = false;
+    bool clamp = true;
+};
+
+void check_ready(crab_engine *e)
+{
+    if (!e->have_tree) fail(CRAB_ERR_STATE, "crab_set_tree has not been called");
+    if (!e->have_aln) fail(CRAB_ERR_STATE, "crab_set_alignment has not been called");
+    if (e->n_leaf_rows > e->aln_rows)
+        fail(CRAB_ERR_ARG, "tree has " + std::to_string(e->n_leaf_rows) + " leaves but the alignment has " +
+                               std::to_string(e->aln_rows) + " rows");
+}
+
+void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL, double *site_lnl, double *by_class_out)
+{
+    const int n = e->n_states;
+    HIP_CHECK(hipSetDevice(e->device));
+
+    // ---- host: eigensystems, one task per rate matrix (replaces the serial loop at lib.rs:163-169) ----
+    const double t0 = now_ms();
+    e->h_eig.ensure((size_t)pl.n_eig * EIG_STRIDE);
+    std::vector<char> ok(pl.n_eig, 1);
+    double *h_eig = e->h_eig.p;
+    const double *Q = pl.Q;
+    parallel_for(pl.n_eig, [&](int i) { ok[i] = spectral_decompose(n, Q + (size_t)i * n * n, pi, h_eig + (size_t)i * EIG_STRIDE) ? 1 : 0; });
+    for (int i = 0; i < pl.n_eig; ++i)
+        if (!ok[i]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(i));
+    e->last_eigen_ms = now_ms() - t0;
+
+    // ---- uploads ----
+    if (!e->ops_uploaded) {
+        e->d_ops.ensure(e->ops.size());
+        HIP_CHECK(hipMemcpyAsync(e->d_ops.p, e->ops.data(), e->ops.size() * sizeof(TreeOp), hipMemcpyHostToDevice, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));  // e->ops is pageable
+        e->ops_uploaded = true;
+    }
+    const size_t n_small = (size_t)pl.M + NS + pl.K;
+    e->h_small.ensure(n_small);
+    double *hs = e->h_small.p;
+    std::memcpy(hs, pl.t_eff.data(), pl.M * sizeof(double));
+    for (int i = 0; i < NS; ++i) hs[pl.M + i] = i < n ? pi[i] : 0.0;
+    for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
+    const size_t n_int = (size_t)pl.M + pl.pidx.size();
+    e->h_int.ensure(n_int);
+    std::memcpy(e->h_int.p, pl.eig_id.data(), pl.M * sizeof(int32_t));
+    std::memcpy(e->h_int.p + pl.M, pl.pidx.data(), pl.pidx.size() * sizeof(int32_t));
+
+    e->d_eig.ensure((size_t)pl.n_eig * EIG_STRIDE);
+    e->d_teff.ensure(pl.M);
+    e->d_pi.ensure(NS);
+    e->d_props.ensure(pl.K);
+    e->d_eig_id.ensure(pl.M);
+    e->d_pidx.ensure(pl.pidx.size());
+    e->d_P.ensure((size_t)pl.M * P_ELEMS);
+    const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
+    const int grid = prune_grid_size(n_tiles * pl.K);
+    e->d_stack.ensure(prune_stack_doubles(grid, e->max_depth));
+    e->d_stack_e.ensure(prune_stack_ints(grid, e->max_depth));
+    e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
+    e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
+    e->d_patlnl.ensure(e->n_pat_pad);
+    e->d_partials.ensure(std::max(1, mix_blocks(e->n_pat)));
+    e->d_lnL.ensure(1);
+    if (pl.by_class) e->d_byclass.ensure((size_t)e->n_pat * pl.K + 1);
+
+    HIP_CHECK(hipMemcpyAsync(e->d_eig.p, h_eig, (size_t)pl.n_eig * EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_teff.p, hs, pl.M * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_pi.p, hs + pl.M, NS * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_props.p, hs + pl.M + NS, pl.K * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_eig_id.p, e->h_int.p, pl.M * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_pidx.p, e->h_int.p + pl.M, pl.pidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+
+    // ---- device ----
+    HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
+    launch_build_p(e->d_eig.p, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, e->stream);
+
+    PruneArgs pa{};
+    pa.ops = e->d_ops.p;
+    pa.n_ops = (int32_t)e->ops.size();
+    pa.P = e->d_P.p;
+    pa.pidx = e->d_pidx.p;
+    pa.n_nodes = e->n_nodes;
+    pa.K = pl.K;
+    pa.codes = e->d_codes.p;
+    pa.n_pat_pad = e->n_pat_pad;
+    pa.pi_pad = e->d_pi.p;
+    pa.n_states = n;
+    pa.stack = e->d_stack.p;
+    pa.stack_e = e->d_stack_e.p;
+    pa.max_depth = std::max(1, e->max_depth);
+    pa.out_f = e->d_f.p;
+    pa.out_e = e->d_e.p;
+    pa.first_gemm_node = e->first_gemm_node;
+    HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
+    launch_prune(pa, grid, e->stream);
+    HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
+
+    e->h_out.ensure(1 + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0));
+    if (pl.by_class) {
+        launch_by_class(e->d_f.p, e->d_e.p, pl.K, e->n_pat, e->n_pat_pad, pl.clamp ? 1 : 0, e->d_byclass.p, e->stream);
+        HIP_CHECK(hipMemcpyAsync(e->h_out.p + 1, e->d_byclass.p, (size_t)e->n_pat * pl.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    } else {
+        MixArgs ma{};
+        ma.f = e->d_f.p;
+        ma.e = e->d_e.p;
+        ma.weights = e->d_weights.p;
+        ma.props = e->d_props.p;
+        ma.K = pl.K;
+        ma.n_pat = e->n_pat;
+        ma.n_pat_pad = e->n_pat_pad;
+        ma.mode = pl.mix_mode;
+        ma.pat_lnl = e->d_patlnl.p;
+        ma.partials = e->d_partials.p;
+        ma.lnL = e->d_lnL.p;
+        if (e->n_pat > 0) {
+            launch_mix(ma, e->stream);
+            HIP_CHECK(hipMemcpyAsync(e->h_out.p, e->d_lnL.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            if (site_lnl)
+                HIP_CHECK(hipMemcpyAsync(e->h_out.p + 1, e->d_patlnl.p, e->n_pat * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        } else {
+            e->h_out.p[0] = 0.0;
+        }
+    }
+    HIP_CHECK(hipEventRecord(e->ev_end, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    HIP_CHECK(hipGetLastError());
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev_begin, e->ev_end));
+    e->last_device_ms = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev_k0, e->ev_k1));
+    e->last_prune_ms = ms;
+    e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
+    e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
+
+    if (pl.by_class) {
+        const double *src = e->h_out.p + 1;
+        for (int64_t s = 0; s < e->n_sites; ++s) {
+            const int64_t p = e->site_to_pat[s];
+            if (p < e->pat_begin || p >= e->pat_end) continue;
+            std::memcpy(by_class_out + (size_t)s * pl.K, src + (size_t)(p - e->pat_begin) * pl.K, pl.K * sizeof(double));
+        }
+    } else {
+        if (lnL) *lnL = e->h_out.p[0];
+        if (site_lnl) {
+            const double *src = e->h_out.p + 1;
+            for (int64_t s = 0; s < e->n_sites; ++s) {
+                const int64_t p = e->site_to_pat[s];
+                if (p < e->pat_begin || p >= e->pat_end) continue;
+                site_lnl[s] = src[p - e->pat_begin];
+            }
+        }
+    }
+}
+
+void plan_site_classes(crab_engine *e, EvalPlan &pl, int K, const double *Q, const double *t)
+{
+    const int nn = e->n_nodes;
+    pl.n_eig = K;
+    pl.Q = Q;
+    pl.K = K;
+    pl.M = K * nn;
+    pl.eig_id.resize(pl.M);
+    pl.t_eff.resize(pl.M);
+    pl.pidx.resize((size_t)K * nn);
+    for (int k = 0; k < K; ++k)
+        for (int v = 0; v < nn; ++v) {
+            const int m = k * nn + v;
+            pl.eig_id[m] = k;
+            pl.t_eff[m] = v == e->root ? 0.0 : t[v];
+            pl.pidx[m] = m;
+        }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int crab_device_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n > 0 ? 1 : 0;
+}
+
+int crab_create(int device, crab_engine **out)
+{
+    if (!out) return CRAB_ERR_ARG;
+    *out = nullptr;
+    std::unique_ptr<crab_engine> e(new (std::nothrow) crab_engine());
+    if (!e) return CRAB_ERR_DEVICE;
+    const int rc = guarded(nullptr, [&] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            throw HipError{"no HIP device available: libcrabml_amd needs an AMD GPU (gfx950); there is no CPU fallback"};
+        }
+        if (device < 0 || device >= n) fail(CRAB_ERR_ARG, "device ordinal " + std::to_string(device) + " out of range");
+        e->device = device;
+        HIP_CHECK(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            throw HipError{std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only"};
+        HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&e->ev_begin));
+        HIP_CHECK(hipEventCreate(&e->ev_end));
+        HIP_CHECK(hipEventCreate(&e->ev_k0));
+        HIP_CHECK(hipEventCreate(&e->ev_k1));
+    });
+    if (rc == CRAB_OK) *out = e.release();
+    return rc;
+}
+
+void crab_destroy(crab_engine *e) { delete e; }
+
+const char *crab_last_error(const crab_engine *e) { return e ? e->err.c_str() : g_last_error.c_str(); }
+
+int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
+                  int n_leaves)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        e->have_tree = false;
+        e->ops_uploaded = false;
+        build_tree(e, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        e->have_tree = true;
+    });
+}
+
+int crab_set_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
+                       int64_t pattern_begin, int64_t pattern_end)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] { load_alignment(e, codes, n_leaves, n_sites, n_states, compress, pattern_begin, pattern_end); });
+}
+
+int64_t crab_n_patterns(const crab_engine *e) { return e ? e->n_pat : 0; }
+int64_t crab_n_patterns_total(const crab_engine *e) { return e ? e->n_pat_total : 0; }
+int64_t crab_n_sites(const crab_engine *e) { return e ? e->n_sites : 0; }
+
+int crab_eval_site_classes(crab_engine *e, int K, const double *Q, const double *proportions, const double *pi,
+                           const double *branch_lengths, unsigned flags, double *lnL, double *site_lnl)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (K < 1 || !Q || !proportions || !pi || !branch_lengths || !lnL) fail(CRAB_ERR_ARG, "crab_eval_site_classes: bad arguments");
+        EvalPlan pl;
+        plan_site_classes(e, pl, K, Q, branch_lengths);
+        pl.props.assign(proportions, proportions + K);
+        pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
+        run_plan(e, pl, pi, lnL, site_lnl, nullptr);
+    });
+}
+
+int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const double *pi, const double *branch_lengths,
+                                unsigned flags, double *out)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (K < 1 || !Q || !pi || !branch_lengths || !out) fail(CRAB_ERR_ARG, "crab_eval_site_lnl_by_class: bad arguments");
+        EvalPlan pl;
+        plan_site_classes(e, pl, K, Q, branch_lengths);
+        pl.by_class = true;
+        pl.clamp = !(flags & CRAB_FLAG_NO_CLAMP);
+        run_plan(e, pl, pi, nullptr, nullptr, out);
+    });
+}
+
+int crab_eval_branch_site(crab_engine *e, const double *Q3, double qfactor_back, double qfactor_fore, double omega0,
+                          double omega2, const double *site_class_freqs, const double *pi, const double *branch_lengths,
+                          const uint8_t *labels, int n_labels, unsigned flags, double *lnL, double *site_lnl)
+{
+    (void)flags;
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (!Q3 || !site_class_freqs || !pi || !branch_lengths || !labels || !lnL) fail(CRAB_ERR_ARG, "crab_eval_branch_site: bad arguments");
+        const int nn = e->n_nodes;
+        if (n_labels != nn - 1)  // branch_site_likelihood.rs:41-47
+            fail(CRAB_ERR_ARG, "Branch labels length " + std::to_string(n_labels) + " must equal n_nodes - 1 = " + std::to_string(nn - 1));
+        for (int v = 0; v < n_labels; ++v)
+            if (labels[v] > 1) fail(CRAB_ERR_ARG, "Invalid branch_label or site_class");  // the reference panics (:100)
+        // eigensystem per (label, class): select_omega (:85-102) followed by the float comparisons of :195-201
+        auto pick = [&](int lab, int k) {
+            const double w = k == 0 ? omega0 : k == 1 ? 1.0 : (lab == 0 ? (k == 2 ? omega0 : 1.0) : omega2);
+            return w == omega0 ? 0 : (w == 1.0 ? 1 : 2);
+        };
+        EvalPlan pl;
+        pl.n_eig = 3;
+        pl.Q = Q3;
+        pl.K = 4;
+        pl.pidx.assign((size_t)4 * nn, 0);
+        pl.props.assign(site_class_freqs, site_class_freqs + 4);
+        pl.mix_mode = MIX_LINEAR;
+        for (int v = 0; v < nn; ++v) {
+            const int lab = v < n_labels ? labels[v] : 0;  // root and beyond: background (:61-70)
+            const double t = (v == e->root ? 0.0 : branch_lengths[v]) * (lab == 0 ? qfactor_back : qfactor_fore);
+            int slot_of_eig[3] = {-1, -1, -1};
+            for (int k = 0; k < 4; ++k) {
+                const int q = pick(lab, k);
+                if (slot_of_eig[q] < 0) {
+                    slot_of_eig[q] = pl.M++;
+                    pl.eig_id.push_back(q);
+                    pl.t_eff.push_back(t);
+                }
+                pl.pidx[(size_t)k * nn + v] = slot_of_eig[q];
+            }
+        }
+        run_plan(e, pl, pi, lnL, site_lnl, nullptr);
+    });
+}
+
+int crab_eval_branch(crab_engine *e, int n_q, const double *Q, const double *pi, const double *branch_lengths,
+                     int n_branch_lengths, unsigned flags, double *lnL, double *site_lnl)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (!Q || !pi || !branch_lengths || !lnL) fail(CRAB_ERR_ARG, "crab_eval_branch: bad arguments");
+        if (n_q != n_branch_lengths)  // lib.rs:377-384
+            fail(CRAB_ERR_ARG, "Q_matrices length (" + std::to_string(n_q) + ") must match branch_lengths length (" +
+                                   std::to_string(n_branch_lengths) + ")");
+        if (n_q != e->n_nodes)  // the reference panics (likelihood.rs:392-398)
+            fail(CRAB_ERR_ARG, "Number of Q matrices (" + std::to_string(n_q) + ") must equal number of nodes (" +
+                                   std::to_string(e->n_nodes) + ")");
+        const int nn = e->n_nodes;
+        EvalPlan pl;
+        pl.n_eig = nn;
+        pl.Q = Q;
+        pl.K = 1;
+        pl.M = nn;
+        pl.eig_id.resize(nn);
+        pl.t_eff.resize(nn);
+        pl.pidx.resize(nn);
+        for (int v = 0; v < nn; ++v) {
+            pl.eig_id[v] = v;
+            pl.t_eff[v] = v == e->root ? 0.0 : branch_lengths[v];
+            pl.pidx[v] = v;
+        }
+        pl.props.assign(1, 1.0);
+        pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
+        run_plan(e, pl, pi, lnL, site_lnl, nullptr);
+    });
+}
+
+int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kernel_ms, double *host_eigen_ms)
+{
+    if (!e) return CRAB_ERR_ARG;
+    if (device_ms) *device_ms = e->last_device_ms;
+    if (prune_kernel_ms) *prune_kernel_ms = e->last_prune_ms;
+    if (host_eigen_ms) *host_eigen_ms = e->last_eigen_ms;
+    return CRAB_OK;
+}
+
+int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)
+{
+    if (!e) return CRAB_ERR_ARG;
+    if (dense_updates) *dense_updates = e->last_dense;
+    if (gather_updates) *gather_updates = e->last_gather;
+    return CRAB_OK;
+}
+
+// ---- host-only introspection (no device needed) ------------------------------------------------
+int crab_compile_tree(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                      int32_t *ops_out, int ops_capacity, int *n_ops, int *max_depth)
+{
+    return guarded(nullptr, [&] {
+        TreeProgram tp;
+        build_tree(&tp, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        if (n_ops) *n_ops = (int)tp.ops.size();
+        if (max_depth) *max_depth = tp.max_depth;
+        if (ops_out) {
+            if ((int)tp.ops.size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
+            for (size_t i = 0; i < tp.ops.size(); ++i) {
+                const TreeOp &o = tp.ops[i];
+                int32_t *r = ops_out + 5 * i;
+                r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot;
+            }
+        }
+    });
+}
+
+int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int64_t *site_to_pattern,
+                           double *pattern_weight, int64_t *first_site, int64_t *n_patterns)
+{
+    return guarded(nullptr, [&] {
+        if (!codes || n_leaves < 1 || n_sites < 0 || n_states < 1 || n_states > NS - 1 || !n_patterns)
+            fail(CRAB_ERR_ARG, "crab_compress_patterns: bad arguments");
+        std::vector<uint8_t> cols;
+        std::vector<int64_t> s2p, first;
+        std::vector<double> cnt;
+        compress_patterns(codes, n_leaves, n_sites, n_states, 1, cols, s2p, first, cnt);
+        *n_patterns = (int64_t)first.size();
+        if (site_to_pattern) std::copy(s2p.begin(), s2p.end(), site_to_pattern);
+        if (pattern_weight) std::copy(cnt.begin(), cnt.end(), pattern_weight);
+        if (first_site) std::copy(first.begin(), first.end(), first_site);
+    });
+}
+
+int crab_spectral_decompose(int n, const double *Q, const double *pi, double *U, double *lam, double *Uinv)
+{
+    return guarded(nullptr, [&] {
+        if (!Q || !pi || !U || !lam || !Uinv || n < 1) fail(CRAB_ERR_ARG, "crab_spectral_decompose: bad arguments");
+        if (!spectral_decompose_plain(n, Q, pi, U, lam, Uinv)) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed");
+    });
+}
+
+// ---- stateless utilities ---------------------------------------------------------------------
+int crab_matrix_exponential(int device, int n, const double *Q, const double *pi, double t, double *P_out)
+{
+    return guarded(nullptr, [&] {
+        if (!Q || !pi || !P_out) fail(CRAB_ERR_ARG, "crab_matrix_exponential: bad arguments");
+        if (n < 1 || n > NS - 1) fail(CRAB_ERR_ARG, "n must be in [1, 63], got " + std::to_string(n));
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) {
+            (void)hipGetLastError();
+            throw HipError{"no HIP device available: libcrabml_amd needs an AMD GPU (gfx950); there is no CPU fallback"};
+        }
+        HIP_CHECK(hipSetDevice(device));
+        std::vector<double> eig(EIG_STRIDE), Pf(P_ELEMS);
+        if (!spectral_decompose(n, Q, pi, eig.data())) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed");
+        DevBuf<double> d_eig, d_t, d_P;
+        DevBuf<int32_t> d_id;
+        struct Cleanup {
+            DevBuf<double> &a, &b, &c;
+            DevBuf<int32_t> &d;
+            ~Cleanup() { a.release(); b.release(); c.release(); d.release(); }
+        } cleanup{d_eig, d_t, d_P, d_id};
+        d_eig.ensure(EIG_STRIDE);
+        d_t.ensure(1);
+        d_P.ensure(P_ELEMS);
+        d_id.ensure(1);
+        const int32_t zero = 0;
+        HIP_CHECK(hipMemcpy(d_eig.p, eig.data(), EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_t.p, &t, sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_id.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice));
+        launch_build_p(d_eig.p, d_id.p, d_t.p, d_P.p, 1, n, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(Pf.data(), d_P.p, P_ELEMS * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) P_out[(size_t)i * n + j] = Pf[p_frag_index(i, j)];
+    });
+}
+
+// build_codon_q_matrix (qmatrix.rs:22-80) over the single-nucleotide neighbour graph of the 61 sense
+// codons in PAML order (codon.rs:63-87,167-220).  Host arithmetic; 526 non-zero off-diagonals.
+int crab_build_codon_q_matrix(double kappa, double omega, const double *pi, int has_factor, double factor, double *Q)
+{
+    if (!pi || !Q) return CRAB_ERR_ARG;
+    static const char aa[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    int sense[61], rank[64], m = 0;
+    for (int c = 0; c < 64; ++c) {
+        rank[c] = -1;
+        if (aa[c] != '*') {
+            sense[m] = c;
+            rank[c] = m++;
+        }
+    }
+    std::fill(Q, Q + 61 * 61, 0.0);
+    for (int i = 0; i < 61; ++i) {
+        const int ci = sense[i];
+        for (int pos = 0; pos < 3; ++pos) {
+            const int sh = 2 * (2 - pos), ni = (ci >> sh) & 3;
+            for (int nj = 0; nj < 4; ++nj) {
+                if (nj == ni) continue;
+                const int cj = (ci & ~(3 << sh)) | (nj << sh);
+                const int j = rank[cj];
+                if (j < 0) continue;
+                double rate = 1.0;
+                if ((ni ^ nj) == 1) rate *= kappa;  // T<->C (0,1) and A<->G (2,3)
+                if (aa[ci] != aa[cj]) rate *= omega;
+                Q[i * 61 + j] = rate * pi[j];
+            }
+        }
+    }
+    for (int i = 0; i < 61; ++i) {
+        double rs = 0.0;
+        for (int j = 0; j < 61; ++j) rs += Q[i * 61 + j];
+        Q[i * 61 + i] = -rs;
+    }
+    double div = factor;
+    if (!has_factor) {
+        double er = 0.0;
+        for (int i = 0; i < 61; ++i) er += pi[i] * Q[i * 61 + i];
+        er = -er;
+        if (!(er > 0.0)) return CRAB_OK;
+        div = er;
+    }
+    for (int i = 0; i < 61 * 61; ++i) Q[i] /= div;
+    return CRAB_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// one-shot layer: the seven PyO3 signatures on top of a handle cache
+// =============================================================================================
+namespace {
+
+struct CacheKey {  // contents, not addresses: callers may re-pack the same alignment on every call
+    int device;
+    int n_leaves;
+    int64_t n_sites;
+    int n_states;
+    uint64_t data_hash, tree_hash;
+    bool operator==(const CacheKey &o) const
+    {
+        return device == o.device && n_leaves == o.n_leaves && n_sites == o.n_sites && n_states == o.n_states &&
+               data_hash == o.data_hash && tree_hash == o.tree_hash;
+    }
+};
+
+struct CacheEntry {
+    CacheKey key;
+    crab_engine *engine;
+};
+
+std::mutex g_cache_mutex;
+std::list<CacheEntry> g_cache;  // most recent first
+constexpr size_t CACHE_MAX = 8;
+
+uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    uint64_t h0 = seed, h1 = seed ^ 0x9e3779b97f4a7c15ull, h2 = seed + 0x632be59bd9b4e019ull, h3 = ~seed;
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, b + i, 32);
+        h0 = (h0 ^ w[0]) * 0x9fb21c651e98df25ull; h0 ^= h0 >> 29;
+        h1 = (h1 ^ w[1]) * 0xd6e8feb86659fd93ull; h1 ^= h1 >> 31;
+        h2 = (h2 ^ w[2]) * 0xc2b2ae3d27d4eb4full; h2 ^= h2 >> 27;
+        h3 = (h3 ^ w[3]) * 0x165667b19e3779f9ull; h3 ^= h3 >> 33;
+    }
+    uint64_t h = mix64(mix64(h0, h1), mix64(h2, h3));
+    for (; i < bytes; ++i) h = mix64(h, b[i]);
+    return mix64(h, bytes);
+}
+
+// Returns a cached engine for this (alignment, tree), creating it on first sight.  The caller holds g_cache_mutex.
+crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                           const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_ids, int *status)
+{
+    *status = CRAB_OK;
+    if (!codes || !parents || n_nodes < 1 || n_leaves < 1 || n_sites < 0) {
+        g_last_error = "bad arguments";
+        *status = CRAB_ERR_ARG;
+        return nullptr;
+    }
+    CacheKey key{device, n_leaves, n_sites, n_states, 0, 0};
+    key.data_hash = hash_words(codes, (size_t)n_leaves * n_sites * sizeof(int32_t), 1);
+    uint64_t th = hash_words(parents, (size_t)n_nodes * sizeof(int32_t), 2);
+    if (node_ids) th = mix64(th, hash_words(node_ids, (size_t)n_nodes * sizeof(int32_t), 3));
+    if (leaf_ids) th = mix64(th, hash_words(leaf_ids, (size_t)n_leaves * sizeof(int32_t), 4));
+    key.tree_hash = th;
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+        if (it->key == key) {
+            g_cache.splice(g_cache.begin(), g_cache, it);
+            return g_cache.front().engine;
+        }
+    crab_engine *e = nullptr;
+    int rc = crab_create(device, &e);
+    if (rc == CRAB_OK) {
+        rc = crab_set_tree(e, n_nodes, node_ids, parents, leaf_ids, n_leaves);
+        if (rc == CRAB_OK) rc = crab_set_alignment(e, codes, n_leaves, n_sites, n_states, 1, 0, -1);
+        if (rc != CRAB_OK) {
+            g_last_error = e->err;
+            crab_destroy(e);
+            e = nullptr;
+        }
+    }
+    *status = rc;
+    if (!e) return nullptr;
+    g_cache.push_front({key, e});
+    while (g_cache.size() > CACHE_MAX) {
+        crab_destroy(g_cache.back().engine);
+        g_cache.pop_back();
+    }
+    return e;
+}
+
+template <typename F>
+int with_cached(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *codes,
+                int n_leaves, int64_t n_sites, const int32_t *leaf_ids, F &&call)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    int status = CRAB_OK;
+    crab_engine *e = cached_engine(device, n_states, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_ids, &status);
+    if (!e) return status;
+    const int rc = call(e);
+    if (rc != CRAB_OK) g_last_error = e->err;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crab_compute_log_likelihood(int device, int n, const double *q, const double *pi, int n_nodes, const int32_t *node_ids,
+                                const int32_t *parents, const double *branch_lengths, const int32_t *codes, int n_leaves,
+                                int64_t n_sites, const int32_t *leaf_node_ids, double *lnL)
+{
+    const double one = 1.0;
+    return with_cached(device, n, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_node_ids,
+                       [&](crab_engine *e) { return crab_eval_site_classes(e, 1, q, &one, pi, branch_lengths, 0, lnL, nullptr); });
+}
+
+int crab_compute_site_class_log_likelihood(int device, int K, int n, const double *q_matrices, const double *proportions,
+                                           const double *pi, int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                                           const double *branch_lengths, const int32_t *codes, int n_leaves, int64_t n_sites,
+                                           const int32_t *leaf_node_ids, double *lnL)
+{
+    return with_cached(device, n, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_node_ids, [&](crab_engine *e) {
+        return crab_eval_site_classes(e, K, q_matrices, proportions, pi, branch_lengths, 0, lnL, nullptr);
+    });
+}
+
+int crab_compute_site_log_likelihoods_by_class(int device, int K, int n, const double *q_matrices, const double *pi,
+                                               int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                                               const double *branch_lengths, const int32_t *codes, int n_leaves,
+                                               int64_t n_sites, const int32_t *leaf_node_ids, double *out)
+{
+    return with_cached(device, n, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_node_ids, [&](crab_engine *e) {
+        return crab_eval_site_lnl_by_class(e, K, q_matrices, pi, branch_lengths, 0, out);
+    });
+}
+
+int crab_compute_branch_site_log_likelihood(int device, int n, const double *q_omega0, const double *q_omega1,
+                                            const double *q_omega2, double qfactor_back, double qfactor_fore, double omega0,
+                                            double omega2, const double *site_class_freqs, const double *pi, int n_nodes,
+                                            const int32_t *node_ids, const int32_t *parents, const double *branch_lengths,
+                                            const uint8_t *branch_labels, int n_labels, const int32_t *codes, int n_leaves,
+                                            int64_t n_sites, const int32_t *leaf_node_ids, double *lnL)
+{
+    if (!q_omega0 || !q_omega1 || !q_omega2 || n < 1) {
+        g_last_error = "bad arguments";
+        return CRAB_ERR_ARG;
+    }
+    std::vector<double> Q3((size_t)3 * n * n);
+    std::memcpy(Q3.data(), q_omega0, sizeof(double) * n * n);
+    std::memcpy(Q3.data() + (size_t)n * n, q_omega1, sizeof(double) * n * n);
+    std::memcpy(Q3.data() + (size_t)2 * n * n, q_omega2, sizeof(double) * n * n);
+    return with_cached(device, n, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_node_ids, [&](crab_engine *e) {
+        return crab_eval_branch_site(e, Q3.data(), qfactor_back, qfactor_fore, omega0, omega2, site_class_freqs, pi,
+                                     branch_lengths, branch_labels, n_labels, 0, lnL, nullptr);
+    });
+}
+
+int crab_compute_log_likelihood_branch(int device, int n, const int32_t *codes, int n_leaves, int64_t n_sites,
+                                       const int32_t *parent_indices, int n_nodes, const int32_t *leaf_node_ids,
+                                       const double *Q_matrices, int n_q, const double *branch_lengths, int n_branch_lengths,
+                                       const double *pi, double *lnL)
+{
+    return with_cached(device, n, n_nodes, nullptr, parent_indices, codes, n_leaves, n_sites, leaf_node_ids, [&](crab_engine *e) {
+        return crab_eval_branch(e, n_q, Q_matrices, pi, branch_lengths, n_branch_lengths, 0, lnL, nullptr);
+    });
+}
+
+void crab_clear_cache(void)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    for (auto &c : g_cache) crab_destroy(c.engine);
+    g_cache.clear();
+}
+
+}  // extern "C"

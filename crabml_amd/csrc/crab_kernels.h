@@ -1,0 +1,102 @@
+// Device-side interface of the likelihood engine: data layouts and kernel launchers.
+// All launchers enqueue on `stream` and never synchronise or allocate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "crab_eigen.h"
+
+namespace crab {
+
+// ---- layouts ------------------------------------------------------------------------------
+// A transition matrix P (64 x 64 padded, P[i][j] = Pr(j at child | i at parent)) is stored in the
+// operand order of v_mfma_f64_16x16x4_f64 with P as the A operand ("fragment order"):
+//     element (i, j) lives at  ((i>>4)*16 + (j>>2))*64 + (i&15) + 16*(j&3)
+// i.e. fragment (mt = i/16, s = j/4) is 64 consecutive doubles, lane l of a wave holding
+// A[m = l&15][k = l>>4].  Column n_states (61) holds the row sums sum_j P[i][j] (used for missing
+// data); rows/columns >= n_states are otherwise zero.
+constexpr int P_ELEMS = NS * NS;  // doubles per matrix (32 KiB)
+
+__host__ __device__ inline int p_frag_index(int i, int j) { return ((i >> 4) * 16 + (j >> 2)) * 64 + (i & 15) + 16 * (j & 3); }
+
+// Conditional likelihoods never touch HBM.  Inside the pruning kernel a wave holds a
+// [64 states x 16 patterns] tile per pattern group: lane l owns pattern (l&15) and the 16 states
+// 4*idx + (l>>4), idx = 0..15 -- the C/D layout of the MFMA, which is also its B-operand layout,
+// so a parent's product consumes the child's tile straight from registers.
+
+// ---- tree program ---------------------------------------------------------------------------
+enum : int32_t { OP_GEMM = 0, OP_LEAF = 1, OP_CONST = 2 };
+enum : int32_t {
+    F_MUL_PROD = 1,   // multiply the new term into the running product of this node
+    F_POP_MUL = 2,    // multiply the new term with stack[slot] (the product saved before a sibling subtree)
+    F_PUSH = 4,       // after this op, save the running product in stack[slot]
+    F_FIN = 8,        // after this op the node is complete: normalise, becomes the operand of the next GEMM
+    F_RESCALE = 16    // normalise the running product now (long runs of children)
+};
+struct alignas(16) TreeOp {
+    int32_t kind;    // OP_*
+    int32_t node;    // child node whose branch this op crosses (index into the class's P table)
+    int32_t flags;   // F_*
+    int32_t arg;     // LEAF: alignment row; GEMM: node of the next GEMM op (-1 none) for prefetch; CONST: 1 -> ones, 0 -> zeros
+    int32_t slot;    // stack slot for F_PUSH / F_POP_MUL
+    int32_t pad[3];
+};
+
+// ---- kernel 1: batched P(t) = U diag(exp(lam t)) U^-1  (replaces matrix.rs:88-112) -----------
+// For m in [0, M): eigensystem eig + eig_id[m]*EIG_STRIDE, time t_eff[m]; writes P + m*P_ELEMS in
+// fragment order with row sums in column n_states.
+void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
+                    hipStream_t stream);
+
+// ---- kernel 2: Felsenstein pruning, whole tree per (pattern tile, class)  ---------------------
+// (replaces likelihood.rs:120-132,176-246 and branch_site_likelihood.rs:222-299)
+struct PruneArgs {
+    const TreeOp *ops;
+    int32_t n_ops;
+    const double *P;          // all matrices of this evaluation
+    const int32_t *pidx;      // [K][n_nodes] -> matrix index in P for (class, node)
+    int32_t n_nodes;
+    int32_t K;
+    const uint8_t *codes;     // [n_rows][n_pat_pad], values 0..n_states (n_states = missing)
+    int64_t n_pat_pad;        // multiple of the tile width
+    const double *pi_pad;     // [64], zero beyond n_states
+    int32_t n_states;
+    double *stack;            // global-memory spill area for saved products
+    int32_t *stack_e;
+    int32_t max_depth;
+    double *out_f;            // [K][n_pat_pad]  scaled site likelihood per class
+    int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
+    int32_t first_gemm_node;  // node of the first GEMM op (-1 if none)
+};
+// Patterns per workgroup for the configuration launch_prune will use.
+int prune_tile_width();
+// Number of workgroups launch_prune will use for n_work = tiles*K work items (persistent grid).
+int prune_grid_size(int64_t n_work);
+// Bytes of stack / stack_e needed for a grid of `grid` workgroups and `max_depth` slots.
+size_t prune_stack_doubles(int grid, int max_depth);
+size_t prune_stack_ints(int grid, int max_depth);
+void launch_prune(const PruneArgs &a, int grid, hipStream_t stream);
+
+// ---- kernel 3: class mixture, log, weighted sum  ---------------------------------------------
+// (replaces likelihood.rs:147-165,281-291,328-335,349-370 and branch_site_likelihood.rs:160-170)
+enum : int32_t { MIX_LOGSUMEXP_CLAMP = 0, MIX_LOGSUMEXP_NOCLAMP = 1, MIX_LINEAR = 2 };
+struct MixArgs {
+    const double *f;         // [K][n_pat_pad]
+    const int32_t *e;
+    const double *weights;   // [n_pat_pad] pattern multiplicities (0 on padding)
+    const double *props;     // [K] class proportions / frequencies
+    int32_t K;
+    int64_t n_pat;
+    int64_t n_pat_pad;
+    int32_t mode;
+    double *pat_lnl;         // [n_pat_pad] per-pattern log-likelihood
+    double *partials;        // [mix_blocks(n_pat)]
+    double *lnL;             // [1]
+};
+int mix_blocks(int64_t n_pat);
+void launch_mix(const MixArgs &a, hipStream_t stream);
+// out[p*K + k] = ln max(f, 1e-300) (clamp != 0) or ln f
+void launch_by_class(const double *f, const int32_t *e, int K, int64_t n_pat, int64_t n_pat_pad, int clamp, double *out,
+                     hipStream_t stream);
+
+}  // namespace crab

@@ -1,0 +1,221 @@
+"""Handle API: one Engine keeps a tree program and a compressed alignment resident on one MI355X.
+
+Thin, allocation-free-per-call wrapper over the crab_* handle functions of include/crabml_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def tree_arrays(tree_structure):
+    """[(node_id, parent_or_None), ...] -> (node_ids int32, parents int32 with -1 for None)."""
+    ids = np.fromiter((int(v) for v, _ in tree_structure), dtype=np.int32, count=len(tree_structure))
+    par = np.fromiter((-1 if p is None else int(p) for _, p in tree_structure), dtype=np.int32, count=len(tree_structure))
+    return ids, par
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        self._h = L.vp()
+        L.check(self._lib.crab_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self.n_nodes = 0
+        self.n_states = 0
+        self.n_sites = 0
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.crab_destroy(self._h)
+            self._h = L.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, status):
+        L.check(status, self._h)
+
+    # -- state ------------------------------------------------------------------------------
+    def set_tree(self, parents, leaf_node_ids, node_ids=None):
+        par, parp = L.i32(parents)
+        leaf, leafp = L.i32(leaf_node_ids)
+        if node_ids is None:
+            idp = None
+        else:
+            ids, idp = L.i32(node_ids)
+        self._check(self._lib.crab_set_tree(self._h, len(par), idp, parp, leafp, len(leaf)))
+        self.n_nodes = len(par)
+
+    def set_tree_structure(self, tree_structure, leaf_node_ids):
+        ids, par = tree_arrays(tree_structure)
+        self.set_tree(par, leaf_node_ids, ids)
+
+    def set_alignment(self, codes, n_states=61, compress=True, pattern_begin=0, pattern_end=-1):
+        codes_, cp = L.i32(codes)
+        if codes_.ndim != 2:
+            raise ValueError("codes must be [n_leaves, n_sites]")
+        self._check(self._lib.crab_set_alignment(self._h, cp, codes_.shape[0], codes_.shape[1], int(n_states),
+                                                 1 if compress else 0, int(pattern_begin), int(pattern_end)))
+        self.n_states = int(n_states)
+        self.n_sites = codes_.shape[1]
+
+    @property
+    def n_patterns(self) -> int:
+        return int(self._lib.crab_n_patterns(self._h))
+
+    @property
+    def n_patterns_total(self) -> int:
+        return int(self._lib.crab_n_patterns_total(self._h))
+
+    # -- evaluations ------------------------------------------------------------------------
+    def _q_stack(self, Q, K=None):
+        Q_ = np.ascontiguousarray(np.asarray(Q, dtype=np.float64))
+        if Q_.ndim == 2:
+            Q_ = Q_[None]
+        n = self.n_states
+        if Q_.shape[1:] != (n, n):
+            raise ValueError(f"Q matrix has shape {Q_.shape[1:]}, expected ({n}, {n})")
+        return Q_, Q_.ctypes.data_as(L.dp)
+
+    def _pi(self, pi):
+        pi_, pp = L.f64(pi)
+        if pi_.shape != (self.n_states,):
+            raise ValueError(f"pi must have length {self.n_states}, got {pi_.shape}")
+        return pi_, pp
+
+    def _bl(self, branch_lengths):
+        bl, blp = L.f64(branch_lengths)
+        if bl.shape != (self.n_nodes,):
+            raise ValueError(f"branch_lengths must have one entry per node ({self.n_nodes}), got {bl.shape}")
+        return bl, blp
+
+    def site_classes(self, Q, proportions, pi, branch_lengths, no_clamp=False, return_sites=False):
+        Q_, Qp = self._q_stack(Q)
+        pr, prp = L.f64(proportions)
+        if len(pr) != Q_.shape[0]:
+            raise ValueError(f"Number of proportions ({len(pr)}) must match number of Q matrices ({Q_.shape[0]})")
+        pi_, pp = self._pi(pi)
+        bl, blp = self._bl(branch_lengths)
+        lnL = C.c_double()
+        site = np.full(self.n_sites, np.nan) if return_sites else None
+        self._check(self._lib.crab_eval_site_classes(self._h, Q_.shape[0], Qp, prp, pp, blp,
+                                                     L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, C.byref(lnL),
+                                                     site.ctypes.data_as(L.dp) if return_sites else None))
+        return (lnL.value, site) if return_sites else lnL.value
+
+    def log_likelihood(self, Q, pi, branch_lengths, **kw):
+        return self.site_classes(np.asarray(Q)[None], [1.0], pi, branch_lengths, **kw)
+
+    def site_lnl_by_class(self, Q, pi, branch_lengths, no_clamp=False):
+        Q_, Qp = self._q_stack(Q)
+        pi_, pp = self._pi(pi)
+        bl, blp = self._bl(branch_lengths)
+        out = np.full((self.n_sites, Q_.shape[0]), np.nan)
+        self._check(self._lib.crab_eval_site_lnl_by_class(self._h, Q_.shape[0], Qp, pp, blp,
+                                                          L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, out.ctypes.data_as(L.dp)))
+        return out
+
+    def branch_site(self, Q3, qfactor_back, qfactor_fore, omega0, omega2, site_class_freqs, pi, branch_lengths, labels,
+                    return_sites=False):
+        Q_, Qp = self._q_stack(Q3)
+        if Q_.shape[0] != 3:
+            raise ValueError("Q3 must hold Q(omega0), Q(1), Q(omega2)")
+        fr, frp = L.f64(site_class_freqs)
+        if len(fr) != 4:
+            raise ValueError("site_class_freqs must have 4 entries")
+        pi_, pp = self._pi(pi)
+        bl, blp = self._bl(branch_lengths)
+        lab, labp = L.u8(labels)
+        lnL = C.c_double()
+        site = np.full(self.n_sites, np.nan) if return_sites else None
+        self._check(self._lib.crab_eval_branch_site(self._h, Qp, float(qfactor_back), float(qfactor_fore), float(omega0),
+                                                    float(omega2), frp, pp, blp, labp, len(lab), 0, C.byref(lnL),
+                                                    site.ctypes.data_as(L.dp) if return_sites else None))
+        return (lnL.value, site) if return_sites else lnL.value
+
+    def branch(self, Q_per_node, pi, branch_lengths, no_clamp=False, return_sites=False):
+        Q_, Qp = self._q_stack(Q_per_node)
+        pi_, pp = self._pi(pi)
+        bl, blp = L.f64(branch_lengths)
+        lnL = C.c_double()
+        site = np.full(self.n_sites, np.nan) if return_sites else None
+        self._check(self._lib.crab_eval_branch(self._h, Q_.shape[0], Qp, pp, blp, len(bl),
+                                               L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, C.byref(lnL),
+                                               site.ctypes.data_as(L.dp) if return_sites else None))
+        return (lnL.value, site) if return_sites else lnL.value
+
+    # -- measurement ------------------------------------------------------------------------
+    def last_timing(self):
+        """(device_ms, prune_kernel_ms, host_eigen_ms) of the last evaluation; HIP events on the engine's stream."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.crab_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def last_work(self):
+        """(dense MFMA updates, gathered leaf updates) of the last evaluation, in pattern x branch x class units."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.crab_last_work(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+# -- host-only helpers (no GPU needed) ----------------------------------------------------------
+OP_FIELDS = ("kind", "node", "flags", "arg", "slot")
+OP_GEMM, OP_LEAF, OP_CONST = 0, 1, 2
+F_MUL_PROD, F_POP_MUL, F_PUSH, F_FIN, F_RESCALE = 1, 2, 4, 8, 16
+
+
+def compile_tree(parents, leaf_node_ids, node_ids=None):
+    """The device program for a tree: int32 array [n_ops, 5] (kind, node, flags, arg, slot) and the stack depth."""
+    lib = L.load()
+    par, parp = L.i32(parents)
+    leaf, leafp = L.i32(leaf_node_ids)
+    idp = None
+    if node_ids is not None:
+        ids, idp = L.i32(node_ids)
+    n_ops, depth = C.c_int(), C.c_int()
+    L.check(lib.crab_compile_tree(len(par), idp, parp, leafp, len(leaf), None, 0, C.byref(n_ops), C.byref(depth)))
+    ops = np.zeros((n_ops.value, 5), dtype=np.int32)
+    L.check(lib.crab_compile_tree(len(par), idp, parp, leafp, len(leaf), ops.ctypes.data_as(L.ip), n_ops.value,
+                                  C.byref(n_ops), C.byref(depth)))
+    return ops, depth.value
+
+
+def compress_patterns(codes, n_states=61):
+    lib = L.load()
+    codes_, cp = L.i32(codes)
+    n_leaves, n_sites = codes_.shape
+    s2p = np.zeros(n_sites, dtype=np.int64)
+    w = np.zeros(n_sites, dtype=np.float64)
+    first = np.zeros(n_sites, dtype=np.int64)
+    n = C.c_int64()
+    L.check(lib.crab_compress_patterns(cp, n_leaves, n_sites, int(n_states), s2p.ctypes.data_as(L.lp), w.ctypes.data_as(L.dp),
+                                       first.ctypes.data_as(L.lp), C.byref(n)))
+    return s2p, w[: n.value].copy(), first[: n.value].copy()
+
+
+def spectral_decompose(Q, pi):
+    lib = L.load()
+    Q_, Qp = L.f64(Q)
+    pi_, pp = L.f64(pi)
+    n = Q_.shape[0]
+    U, lam, Uinv = np.empty((n, n)), np.empty(n), np.empty((n, n))
+    L.check(lib.crab_spectral_decompose(n, Qp, pp, U.ctypes.data_as(L.dp), lam.ctypes.data_as(L.dp), Uinv.ctypes.data_as(L.dp)))
+    return U, lam, Uinv
+
+
+def device_available() -> bool:
+    return bool(L.load().crab_device_available())

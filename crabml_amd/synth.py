@@ -1,0 +1,157 @@
+"""Seeded synthetic trees and codon alignments for benchmarks and large parity tests.
+
+The reference's simulators (src/crabml/simulate/) never touch the native core and are out
+of scope; this is a compact generator of our own, following SURVEY.md section 8(d): random binary
+topology by random joins with a trifurcating root (bushy, never a caterpillar), branch lengths
+Exp(mean), pi ~ Dirichlet(5), kappa = 2.5, sequences evolved down the tree under the model that
+is then evaluated, 1 % gap codons.  Output is already in boundary numbering: leaves are nodes
+0..N-1 (row i of ``codes`` belongs to node i), internal nodes follow children-before-parents,
+the root is last.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import models
+from .io import GAP_CODE
+
+
+def random_tree(n_taxa: int, rng, mean_branch: float):
+    """parent[v] (-1 root), branch_lengths[v] (0 at root); trifurcating root; needs n_taxa >= 3."""
+    if n_taxa < 3:
+        raise ValueError("n_taxa must be >= 3")
+    n_nodes = 2 * n_taxa - 2
+    parent = np.full(n_nodes, -1, dtype=np.int32)
+    active = list(range(n_taxa))
+    nxt = n_taxa
+    while len(active) > 3:
+        i, j = rng.choice(len(active), size=2, replace=False)
+        a, b = active[i], active[j]
+        parent[a] = parent[b] = nxt
+        active = [x for k, x in enumerate(active) if k != i and k != j] + [nxt]
+        nxt += 1
+    root = nxt
+    for a in active:
+        parent[a] = root
+    assert root == n_nodes - 1
+    bl = rng.exponential(mean_branch, size=n_nodes)
+    bl = np.maximum(bl, 1e-4)
+    bl[root] = 0.0
+    return parent, bl
+
+
+def _transition_matrix(Q, pi, t):
+    sq = np.sqrt(pi)
+    S = Q * sq[:, None] / sq[None, :]
+    S = 0.5 * (S + S.T)
+    lam, V = np.linalg.eigh(S)
+    P = (V * np.exp(lam * t)) @ V.T
+    P = P * sq[None, :] / sq[:, None]
+    P = np.clip(P, 0.0, None)
+    return P / P.sum(axis=1, keepdims=True)
+
+
+def _sample_children(P, parent_states, rng):
+    cum = np.cumsum(P, axis=1)
+    cum[:, -1] = 1.0
+    u = rng.random(parent_states.shape[0])
+    out = np.empty_like(parent_states)
+    step = 1 << 16
+    for s in range(0, len(parent_states), step):
+        rows = cum[parent_states[s:s + step]]
+        out[s:s + step] = (u[s:s + step, None] > rows).sum(axis=1)
+    return np.minimum(out, P.shape[0] - 1)
+
+
+def evolve(parent, bl, pi, site_Q_of_node, site_class, n_sites, rng, gap_fraction=0.01):
+    """site_Q_of_node(v, k) -> (matrix id, rate matrix, effective time) for the branch above v and class k."""
+    n_nodes = len(parent)
+    n_taxa = (n_nodes + 2) // 2
+    root = n_nodes - 1
+    states = np.zeros((n_nodes, n_sites), dtype=np.int64)
+    states[root] = rng.choice(61, size=n_sites, p=pi)
+    classes = np.unique(site_class)
+    class_sites = {int(k): np.flatnonzero(site_class == k) for k in classes}
+    for v in range(n_nodes - 2, -1, -1):  # parents have larger ids than children
+        p = parent[v]
+        cache = {}  # classes may share a matrix on one branch (Model A)
+        for k, idx in class_sites.items():
+            qid, Q, teff = site_Q_of_node(v, k)
+            if qid not in cache:
+                cache[qid] = _transition_matrix(Q, pi, teff)
+            states[v, idx] = _sample_children(cache[qid], states[p, idx], rng)
+    codes = states[:n_taxa].astype(np.int32)
+    if gap_fraction > 0:
+        mask = rng.random(codes.shape) < gap_fraction
+        codes[mask] = GAP_CODE
+    return np.ascontiguousarray(codes)
+
+
+def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: float | None = None, gap_fraction=0.01):
+    """model in {"M0", "M7", "M8", "ModelA", "free-ratio"}.  Returns a namespace with everything the
+    boundary needs (parent, leaf_node_ids, tree_structure, branch_lengths, codes, pi, Q, proportions, ...)."""
+    rng = np.random.default_rng(seed)
+    n_branches = 2 * n_taxa - 3
+    if mean_branch is None:
+        mean_branch = min(0.1, 10.0 / n_branches)
+    parent, bl = random_tree(n_taxa, rng, mean_branch)
+    n_nodes = len(parent)
+    pi = rng.dirichlet(5.0 * np.ones(61))
+    kappa = 2.5
+    case = SimpleNamespace(model=model, n_taxa=n_taxa, n_sites=n_sites, seed=seed, parent=parent, branch_lengths=bl, pi=pi,
+                           kappa=kappa, n_nodes=n_nodes, leaf_node_ids=np.arange(n_taxa, dtype=np.int32),
+                           tree_structure=[(v, None if parent[v] < 0 else int(parent[v])) for v in range(n_nodes)],
+                           tree_length=float(bl.sum()))
+    if model in ("M0", "M7", "M8"):
+        if model == "M0":
+            m = models.M0CodonModel(kappa=kappa, omega=0.3, pi=pi)
+            Q, props = np.stack([m.get_Q_matrix()]), np.array([1.0])
+        elif model == "M7":
+            m = models.M7CodonModel(kappa=kappa, p_beta=0.7, q_beta=1.5, ncatG=10, pi=pi)
+            Q, props = np.stack(m.get_Q_matrices()), np.array(m.get_site_classes()[0])
+        else:
+            m = models.M8CodonModel(kappa=kappa, p0=0.9, p_beta=0.7, q_beta=1.5, omega_s=2.5, ncatG=10, pi=pi)
+            Q, props = np.stack(m.get_Q_matrices()), np.array(m.get_site_classes()[0])
+        site_class = rng.choice(len(props), size=n_sites, p=props / props.sum())
+        case.Q, case.proportions = Q, props
+        case.codes = evolve(parent, bl, pi, lambda v, k: (k, Q[k], bl[v]), site_class, n_sites, rng, gap_fraction)
+    elif model == "ModelA":
+        p0, p1, w0, w2 = 0.5, 0.3, 0.1, 3.0
+        labels = np.zeros(n_nodes - 1, dtype=np.uint8)
+        internals = np.arange(n_taxa, n_nodes - 1)
+        fg_root = int(rng.choice(internals)) if len(internals) else 0
+        below = np.zeros(n_nodes, dtype=bool)
+        below[fg_root] = True
+        for v in range(n_nodes - 2, -1, -1):
+            if parent[v] >= 0 and below[parent[v]]:
+                below[v] = True
+        labels[below[: n_nodes - 1]] = 1
+        if labels.all() or not labels.any():
+            labels[:] = 0
+            labels[0] = 1
+        ma = models.BranchSiteModelA(pi, np.concatenate([labels.astype(int)]))
+        freqs = ma.compute_site_class_frequencies(p0, p1)
+        qb, qf = ma.compute_qfactors(kappa, p0, p1, w0, w2)
+        Q3 = np.stack(ma.unnormalised_Qs(kappa, w0, w2))
+        site_class = rng.choice(4, size=n_sites, p=freqs)
+
+        def q_of(v, k):
+            lab = labels[v] if v < n_nodes - 1 else 0
+            w = ma.get_omega_for_branch_class(int(lab), k, w0, w2)
+            q = 0 if w == w0 else (1 if w == 1.0 else 2)
+            return q, Q3[q], bl[v] * (qf if lab else qb)
+
+        case.Q3, case.qfactors, case.site_class_freqs, case.branch_labels = Q3, (qb, qf), freqs, labels
+        case.omega0, case.omega2 = w0, w2
+        case.codes = evolve(parent, bl, pi, q_of, site_class, n_sites, rng, gap_fraction)
+    elif model == "free-ratio":
+        omegas = np.exp(rng.normal(np.log(0.3), 0.5, size=n_nodes - 1))
+        bm = models.CodonBranchModel(pi, np.zeros(n_nodes, dtype=int), free_ratio=True, n_nodes=n_nodes)
+        Qn = bm.get_Q_matrices(kappa, omegas)
+        case.Q_per_node, case.omegas = Qn, omegas
+        case.codes = evolve(parent, bl, pi, lambda v, k: (0, Qn[v], bl[v]), np.zeros(n_sites, dtype=int), n_sites, rng, gap_fraction)
+    else:
+        raise ValueError(f"unknown model {model}")
+    return case

@@ -1,0 +1,166 @@
+/*
+ * crabml_amd.h -- C ABI of the MI355X codon-likelihood engine (libcrabml_amd.so).
+ *
+ * This is the drop-in boundary for crabML's native likelihood core: every entry
+ * point below replaces one function of the PyO3 module `crabml.crabml_rust`
+ * (/root/reference/rust/src/lib.rs:468-478) or a piece of state that module
+ * rebuilds on every call.  Plain pointers and sizes only; no exception crosses
+ * the ABI; every function returns a crab_status (0 = ok) and leaves a message
+ * retrievable with crab_last_error().  All matrices are row-major double.
+ *
+ * Two layers:
+ *   (1) a handle API (crab_create / crab_set_tree / crab_set_alignment /
+ *       crab_eval_*), which keeps the tree program, the compressed site patterns
+ *       and all workspaces resident in HBM between evaluations -- the reference
+ *       boundary is stateless and re-uploads everything per call
+ *       (lib.rs:162-187, likelihood.rs:97-106);
+ *   (2) one-shot functions with the argument lists of the seven PyO3 functions,
+ *       built on (1) with an internal handle cache keyed on the alignment buffer.
+ *
+ * Conventions shared by all calls
+ *   tree      n_nodes entries (node_ids[k], parents[k]); parents[k] = -1 for "None".
+ *             node_ids may be NULL (= 0..n_nodes-1).  Children keep their order of
+ *             appearance; the root is the first node without a parent
+ *             (likelihood.rs:36-81).  Any arity.
+ *   leaves    leaf_node_ids[r] is the node that owns row r of the alignment
+ *             (likelihood.rs:120-132).
+ *   codes     int32 [n_leaves x n_sites] row-major; a code outside [0, n_states)
+ *             is missing data (all-ones conditional likelihood).
+ *   t         branch_lengths[v] = length of the branch above node v; the root's
+ *             entry is ignored.
+ *   n_states  <= 63 (61 for codons); padded to 64 on the device.
+ */
+#ifndef CRABML_AMD_H
+#define CRABML_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct crab_engine crab_engine;
+
+typedef enum {
+    CRAB_OK = 0,
+    CRAB_ERR_ARG = 1,        /* shape / value errors: the reference raises ValueError or panics */
+    CRAB_ERR_NO_ROOT = 2,    /* "No root node found" (likelihood.rs:57-59) */
+    CRAB_ERR_EIGEN = 3,      /* "Eigendecomposition failed" (matrix.rs:54-55) */
+    CRAB_ERR_DEVICE = 4,     /* HIP runtime error, no GPU, out of memory */
+    CRAB_ERR_STATE = 5       /* call order: tree / alignment not set */
+} crab_status;
+
+/* flags for crab_eval_* */
+#define CRAB_FLAG_NO_CLAMP 1u   /* drop the reference's max(f, 1e-300) clamps (likelihood.rs:161,332,356,450):
+                                   exact log-likelihoods on trees long enough to underflow fp64 */
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* device = HIP device ordinal (one engine per process/GPU is the intended use). */
+int crab_create(int device, crab_engine **out);
+void crab_destroy(crab_engine *e);
+/* Message of the last failing call on `e` (or of the last failing call without a handle if e == NULL). */
+const char *crab_last_error(const crab_engine *e);
+/* 1 if a HIP device is usable, 0 otherwise (never faults). */
+int crab_device_available(void);
+
+/* ---- state: replaces Tree::from_structure (likelihood.rs:36-81) and the per-call
+ *      leaf initialisation (likelihood.rs:120-132) -------------------------------- */
+int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                  const int32_t *leaf_node_ids, int n_leaves);
+/* Uploads the alignment once.  compress != 0 collapses identical columns into weighted
+ * site patterns (the reference computes every column; results are identical up to summation order).
+ * pattern_begin/pattern_end select a slice of the (compressed) pattern list for multi-GPU sharding:
+ * pass 0, -1 for all patterns. */
+int crab_set_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
+                       int compress, int64_t pattern_begin, int64_t pattern_end);
+int64_t crab_n_patterns(const crab_engine *e);       /* patterns held by this engine (after slicing) */
+int64_t crab_n_patterns_total(const crab_engine *e); /* patterns of the whole alignment */
+int64_t crab_n_sites(const crab_engine *e);
+
+/* ---- evaluations ----------------------------------------------------------- */
+/* compute_site_class_log_likelihood (lib.rs:146-191 -> likelihood.rs:256-292,349-370).
+ * K = 1 with proportions = {1.0} is compute_log_likelihood (lib.rs:97-127 -> likelihood.rs:109-166).
+ * Q: [K][n][n]; site_lnl: optional [n_sites] per-site log-likelihoods (NULL to skip;
+ * only sites whose pattern lies in this engine's slice are written, others are left untouched). */
+int crab_eval_site_classes(crab_engine *e, int K, const double *Q, const double *proportions, const double *pi,
+                           const double *branch_lengths, unsigned flags, double *lnL, double *site_lnl);
+
+/* compute_site_log_likelihoods_by_class (lib.rs:214-258 -> likelihood.rs:303-338):
+ * out[s*K + k] = ln max(f_{k,s}, 1e-300), shape [n_sites][K]. */
+int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const double *pi,
+                                const double *branch_lengths, unsigned flags, double *out);
+
+/* compute_branch_site_log_likelihood (lib.rs:287-345 -> branch_site_likelihood.rs:115-299).
+ * Q3: [3][n][n] = Q(omega0), Q(1), Q(omega2), unnormalised; labels[n_labels], n_labels must be
+ * n_nodes-1, indexed by node id, values 0/1.  lnL = sum_s ln sum_k freqs[k] f_{k,s}; no clamp. */
+int crab_eval_branch_site(crab_engine *e, const double *Q3, double qfactor_back, double qfactor_fore,
+                          double omega0, double omega2, const double *site_class_freqs, const double *pi,
+                          const double *branch_lengths, const uint8_t *labels, int n_labels, unsigned flags,
+                          double *lnL, double *site_lnl);
+
+/* compute_log_likelihood_branch (lib.rs:363-430 -> likelihood.rs:385-455): one Q per node.
+ * n_q must equal n_nodes and n_branch_lengths. */
+int crab_eval_branch(crab_engine *e, int n_q, const double *Q, const double *pi, const double *branch_lengths,
+                     int n_branch_lengths, unsigned flags, double *lnL, double *site_lnl);
+
+/* Timing of the last crab_eval_* on this engine, in milliseconds (HIP events on the engine's
+ * stream): whole device section, and the pruning kernel alone.  For bench.py's roofline block. */
+int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kernel_ms, double *host_eigen_ms);
+/* Static facts about the pruning launch of the last evaluation: number of dense
+ * (pattern x branch x class) updates executed as MFMA products, and of leaf-edge updates done as gathers. */
+int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates);
+
+/* ---- stateless utilities ----------------------------------------------------- */
+/* matrix_exponential (lib.rs:61-79 -> matrix.rs:31-102): P = exp(Q t), computed on the device
+ * with the same batched kernel the evaluations use.  P_out: [n][n]. */
+int crab_matrix_exponential(int device, int n, const double *Q, const double *pi, double t, double *P_out);
+/* build_codon_q_matrix_py (lib.rs:445-463 -> qmatrix.rs:22-80).  Host only. */
+int crab_build_codon_q_matrix(double kappa, double omega, const double *pi, int has_normalization_factor,
+                              double normalization_factor, double *Q_out);
+
+/* ---- host-only introspection: the pieces of host logic, callable without a GPU ---- */
+/* Tree::from_structure + post-order (likelihood.rs:36-81) compiled into the device program.
+ * ops_out receives 5 int32 per op {kind, node, flags, arg, slot} (see crab_kernels.h);
+ * pass ops_out = NULL to query n_ops first. */
+int crab_compile_tree(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
+                      int n_leaves, int32_t *ops_out, int ops_capacity, int *n_ops, int *max_depth);
+/* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
+int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
+                           int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,
+                           int64_t *n_patterns);
+/* CachedQMatrix::new (matrix.rs:31-75) as the engine does it on the host: U, lam, U^-1 (n x n, n, n x n). */
+int crab_spectral_decompose(int n, const double *Q, const double *pi, double *U, double *lam, double *Uinv);
+
+/* ---- one-shot forms with the argument lists of the PyO3 functions ------------- */
+/* Each looks up (or creates) a cached engine for (codes pointer, shape, checksum, tree) on `device`. */
+int crab_compute_log_likelihood(int device, int n, const double *q, const double *pi, int n_nodes,
+                                const int32_t *node_ids, const int32_t *parents, const double *branch_lengths,
+                                const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_node_ids,
+                                double *lnL);
+int crab_compute_site_class_log_likelihood(int device, int K, int n, const double *q_matrices,
+                                           const double *proportions, const double *pi, int n_nodes,
+                                           const int32_t *node_ids, const int32_t *parents,
+                                           const double *branch_lengths, const int32_t *codes, int n_leaves,
+                                           int64_t n_sites, const int32_t *leaf_node_ids, double *lnL);
+int crab_compute_site_log_likelihoods_by_class(int device, int K, int n, const double *q_matrices, const double *pi,
+                                               int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                                               const double *branch_lengths, const int32_t *codes, int n_leaves,
+                                               int64_t n_sites, const int32_t *leaf_node_ids, double *out);
+int crab_compute_branch_site_log_likelihood(int device, int n, const double *q_omega0, const double *q_omega1,
+                                            const double *q_omega2, double qfactor_back, double qfactor_fore,
+                                            double omega0, double omega2, const double *site_class_freqs,
+                                            const double *pi, int n_nodes, const int32_t *node_ids,
+                                            const int32_t *parents, const double *branch_lengths,
+                                            const uint8_t *branch_labels, int n_labels, const int32_t *codes,
+                                            int n_leaves, int64_t n_sites, const int32_t *leaf_node_ids, double *lnL);
+int crab_compute_log_likelihood_branch(int device, int n, const int32_t *codes, int n_leaves, int64_t n_sites,
+                                       const int32_t *parent_indices, int n_nodes, const int32_t *leaf_node_ids,
+                                       const double *Q_matrices, int n_q, const double *branch_lengths,
+                                       int n_branch_lengths, const double *pi, double *lnL);
+/* Drops every cached one-shot engine (frees their HBM). */
+void crab_clear_cache(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRABML_AMD_H */

@@ -1,0 +1,84 @@
+"""Shared helpers for the test-suite: fixture loading, tolerances, a numpy emulator of the device program."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+DATA = os.path.join(GOLDEN, "data")
+
+LYSOZYME_MODELS = ["m0", "m1a", "m2a", "m3", "m4", "m5", "m6", "m7", "m8", "m8a", "m9"]
+SITE_MODEL_CASES = [f"lysozyme_{m}" for m in LYSOZYME_MODELS] + ["hiv_m8a", "lysin_m2a_gaps", "synthetic_edge"]
+
+# Tolerances of BASELINE.json's north_star: per-pattern log-likelihoods within 1e-10 relative,
+# total lnL within 1e-6 absolute.
+SITE_RTOL = 1e-10
+TOTAL_ATOL = 1e-6
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def tree_structure(parent):
+    return [(i, None if p < 0 else int(p)) for i, p in enumerate(parent)]
+
+
+def leaf_ids(case):
+    return list(range(case["sequences"].shape[0]))
+
+
+def assert_by_class_close(got, ref, what="", rtol=SITE_RTOL):
+    """Compare [S, K] tables of ln f_{k,s}.
+
+    Entries within e^-7 of their site's best class must agree to 1e-10 relative in ln f.  Entries far
+    below the best class are differences of O(1e-16)-accurate transition probabilities and carry the
+    rounding noise of whichever eigen-solver / expm produced them (the reference's Rust and Python
+    paths differ there too); those are compared in probability space against the site's best class.
+    """
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    best = ref.max(axis=1, keepdims=True)
+    near = ref >= best - 7.0
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)  # ln f = 0 on an all-missing column
+    assert np.all(rel[near] <= rtol), f"{what}: well-conditioned entries differ, max rel {rel[near].max():.3e}"
+    d = np.abs(np.exp(got - best) - np.exp(ref - best))
+    assert np.all(d[~near] <= 1e-9), f"{what}: far-tail entries differ by {d[~near].max():.3e} of the site's best class"
+
+
+# -----------------------------------------------------------------------------------------------
+# numpy emulator of the device tree program (crabml_amd/csrc/crab_kernels.h: TreeOp)
+# -----------------------------------------------------------------------------------------------
+OP_GEMM, OP_LEAF, OP_CONST = 0, 1, 2
+F_MUL_PROD, F_POP_MUL, F_PUSH, F_FIN, F_RESCALE = 1, 2, 4, 8, 16
+
+
+def emulate_program(ops, P_of_node, codes, pi, n_states=61):
+    """Run the op list exactly as prune_kernel does (minus rescaling, which is exact) and return f[s].
+
+    P_of_node[v] is the n x n transition matrix on the branch above node v; codes [n_rows, S]."""
+    S = codes.shape[1]
+    cur = prod = None
+    stack = {}
+    for kind, node, flags, arg, slot in ops:
+        if kind == OP_GEMM:
+            t = cur @ P_of_node[node].T
+        elif kind == OP_LEAF:
+            c = codes[arg]
+            valid = (c >= 0) & (c < n_states)
+            t = np.where(valid[:, None], P_of_node[node].T[np.where(valid, c, 0)], P_of_node[node].sum(axis=1)[None, :])
+        else:
+            t = np.full((S, n_states), float(arg))
+        if flags & F_MUL_PROD:
+            t = t * prod
+        if flags & F_POP_MUL:
+            t = t * stack.pop(slot)
+        prod = t
+        if flags & F_PUSH:
+            assert slot not in stack, "stack slot overwritten while live"
+            stack[slot] = prod
+        if flags & F_FIN:
+            cur = prod
+    assert not stack, "stack not empty at the end of the program"
+    return cur @ pi
