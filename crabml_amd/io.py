@@ -283,6 +283,6 @@ class Tree:
             if self.has_label is not None and self.has_label[v]:
                 s += f"#{int(self.label[v])}"
             if self.parent[v] >= 0:
-                s += f":{self.branch_length[v]!r}"
+                s += f":{float(self.branch_length[v])!r}"
             return s
         return rec(self.root) + ";"

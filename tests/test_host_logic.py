@@ -1,0 +1,308 @@
+"""CPU-side checks of everything in the product that is not a kernel: the C-ABI library loads and exports
+what include/crabml_amd.h declares, the host eigensolver, the tree -> device-program compiler, pattern
+compression, and the Python input producers (io, models, adapter) against the reference's fixtures.
+No compute entry point is called here (there is no GPU in this tier)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from util import DATA, LYSOZYME_MODELS, emulate_program, leaf_ids, load_case, tree_structure
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------
+# the boundary
+# ---------------------------------------------------------------------------------------------
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "crabml_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crab_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from crabml_amd import _lib
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/crabml_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes prototypes and header disagree"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a device every compute entry point must fail with CRAB_ERR_DEVICE; with one, create succeeds."""
+    from crabml_amd import _lib
+    from crabml_amd.engine import Engine, device_available
+    if device_available():
+        Engine(0).close()
+        return
+    with pytest.raises(_lib.CrabError) as ei:
+        Engine(0)
+    assert ei.value.status == _lib.CRAB_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+    from crabml_amd import crabml_rust as shim
+    c = load_case("lysozyme_m0")
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        shim.compute_log_likelihood(c["Q"][0], c["pi"], tree_structure(c["parent"]), list(c["branch_lengths"]), None,
+                                    c["sequences"], leaf_ids(c))
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        shim.matrix_exponential(c["Q"][0], c["pi"], 0.1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "crabml_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("independent of oracle/", ""), f"{f} mentions the oracle"
+
+
+# ---------------------------------------------------------------------------------------------
+# host eigensolver (product) against the oracle's
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lysozyme_m0", "lysozyme_m7", "lysozymeLarge_modelA"])
+def test_spectral_decomposition_reconstructs_q_and_p(oracle, name):
+    from crabml_amd.engine import spectral_decompose
+    c = load_case(name)
+    pi = c["pi"]
+    for Q in c["Q"]:
+        U, lam, Ui = spectral_decompose(Q, pi)
+        scale = np.abs(Q).max()
+        np.testing.assert_allclose((U * lam) @ Ui, Q, atol=3e-14 * scale)
+        np.testing.assert_allclose(U @ Ui, np.eye(61), atol=1e-13)
+        assert abs(lam.max()) < 1e-13 * scale and (lam <= 1e-13 * scale).all()
+        for t in (0.0, 0.03, 1.5):
+            np.testing.assert_allclose((U * np.exp(lam * t)) @ Ui, oracle.matrix_exponential(Q, pi, t), atol=2e-14)
+
+
+def test_spectral_decomposition_rejects_bad_pi():
+    from crabml_amd import _lib
+    from crabml_amd.engine import spectral_decompose
+    c = load_case("lysozyme_m0")
+    pi = c["pi"].copy()
+    pi[3] = 0.0
+    with pytest.raises(_lib.CrabError) as ei:
+        spectral_decompose(c["Q"][0], pi)
+    assert ei.value.status == _lib.CRAB_ERR_EIGEN
+
+
+# ---------------------------------------------------------------------------------------------
+# tree -> program
+# ---------------------------------------------------------------------------------------------
+def _p_of_node(oracle, Q, pi, bl):
+    # the oracle's own P(t), entry for entry: a different summation order inside U diag(e^{lam t}) U^-1 alone
+    # moves ill-conditioned sites by 1e-10 relative, which would mask what this test is about (the program)
+    return [oracle.matrix_exponential(Q, pi, t) for t in bl]
+
+
+@pytest.mark.parametrize("name", ["lysozyme_m0", "hiv_m8a", "lysin_m2a_gaps", "synthetic_edge", "lysozymeLarge_modelA"])
+def test_compiled_program_computes_the_pruning_recursion(oracle, name):
+    """Interpreting the op list in numpy must give the oracle's per-site likelihoods: validates op order,
+    PUSH/POP slots, leaf rows and FIN placement for bi- and multifurcating trees with missing data."""
+    from crabml_amd.engine import compile_tree
+    c = load_case(name)
+    parent, seq = c["parent"], c["sequences"]
+    ops, depth = compile_tree(parent, leaf_ids(c))
+    Q = c["Q"][0]
+    P = _p_of_node(oracle, Q, c["pi"], c["branch_lengths"])
+    f = emulate_program(ops, P, seq, c["pi"])
+    _, site = oracle.compute_log_likelihood(Q, c["pi"], tree_structure(parent), c["branch_lengths"], None, seq, leaf_ids(c),
+                                            return_sites=True)
+    np.testing.assert_allclose(np.log(f), site, rtol=1e-12, atol=1e-13)
+    n_leaves = seq.shape[0]
+    kinds = ops[:, 0]
+    assert (kinds == 1).sum() == n_leaves                       # every leaf edge is a gather
+    assert (kinds == 0).sum() == len(parent) - 1 - n_leaves     # every internal edge is one MFMA product
+    assert ops[-1, 2] & 8                                       # the root finishes the program
+    assert depth <= max(1, int(np.ceil(np.log2(n_leaves))))     # Sethi-Ullman bound
+
+
+def test_program_of_random_trees_and_stack_depth(oracle):
+    from crabml_amd import synth
+    from crabml_amd.engine import compile_tree
+    for seed, n_taxa in [(1, 5), (2, 17), (3, 64), (4, 200)]:
+        case = synth.make_case("M0", n_taxa, 40, seed=seed, mean_branch=0.05)
+        ops, depth = compile_tree(case.parent, case.leaf_node_ids)
+        assert depth <= int(np.ceil(np.log2(n_taxa)))
+        P = _p_of_node(oracle, case.Q[0], case.pi, case.branch_lengths)
+        f = emulate_program(ops, P, case.codes, case.pi)
+        _, site = oracle.compute_log_likelihood(case.Q[0], case.pi, case.tree_structure, case.branch_lengths, None, case.codes,
+                                                case.leaf_node_ids, return_sites=True)
+        np.testing.assert_allclose(np.log(f), site, rtol=1e-11)
+        # prefetch chain: every GEMM names the next GEMM's node
+        gemm = ops[ops[:, 0] == 0]
+        assert list(gemm[:-1, 3]) == list(gemm[1:, 1]) and gemm[-1, 3] == -1
+
+
+def test_caterpillar_and_star_trees():
+    from crabml_amd.engine import compile_tree
+    n = 50
+    # caterpillar: ((((0,1),2),3)...) -- stack depth 0, no pushes
+    parent = np.full(2 * n - 1, -1, dtype=np.int32)
+    nxt = n
+    cur = 0
+    for leaf in range(1, n):
+        parent[cur] = parent[leaf] = nxt
+        cur = nxt
+        nxt += 1
+    ops, depth = compile_tree(parent, np.arange(n))
+    assert depth == 0 and not (ops[:, 2] & 4).any()
+    # star: one root, n leaves -- rescale flags appear every 4th term
+    parent = np.full(n + 1, n, dtype=np.int32)
+    parent[n] = -1
+    ops, depth = compile_tree(parent, np.arange(n))
+    assert depth == 0 and len(ops) == n and ((ops[:, 2] & 16) != 0).sum() == n // 4
+
+
+def test_tree_errors_match_reference_behaviour():
+    from crabml_amd import _lib
+    from crabml_amd.engine import compile_tree
+    with pytest.raises(_lib.CrabError, match="No root node found") as ei:   # likelihood.rs:57-59
+        compile_tree([1, 2, 0], [0])
+    assert ei.value.status == _lib.CRAB_ERR_NO_ROOT
+    with pytest.raises(_lib.CrabError):
+        compile_tree([5, -1], [0])           # parent id out of range
+    with pytest.raises(_lib.CrabError):
+        compile_tree([-1, 0, 0], [0, 1, 9])  # leaf id out of range
+
+
+def test_children_keep_order_of_appearance_with_explicit_node_ids(oracle):
+    """tree_structure may list nodes in any order (likelihood.rs:49-54 keeps children in list order)."""
+    from crabml_amd.engine import compile_tree
+    c = load_case("synthetic_edge")
+    parent = c["parent"]
+    perm = np.random.default_rng(0).permutation(len(parent))
+    ops_a, _ = compile_tree(parent, leaf_ids(c))
+    ops_b, _ = compile_tree(parent[perm], leaf_ids(c), node_ids=perm)
+    P = _p_of_node(oracle, c["Q"][0], c["pi"], c["branch_lengths"])
+    fa = emulate_program(ops_a, P, c["sequences"], c["pi"])
+    fb = emulate_program(ops_b, P, c["sequences"], c["pi"])
+    np.testing.assert_allclose(fa, fb, rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# pattern compression
+# ---------------------------------------------------------------------------------------------
+def test_pattern_compression():
+    from crabml_amd.engine import compress_patterns
+    c = load_case("lysozymeLarge_modelA")
+    s2p, w, first = compress_patterns(c["sequences"])
+    assert len(w) == 86 and w.sum() == 130          # PAML's own pattern count for this alignment (lnf header)
+    np.testing.assert_array_equal(c["sequences"][:, first][:, s2p], c["sequences"])
+    assert list(first) == sorted(first)             # patterns are numbered by first appearance
+    # missing-data codes are one symbol
+    e = load_case("synthetic_edge")
+    seq = e["sequences"].copy()
+    s2p, w, first = compress_patterns(seq)
+    assert s2p[20] == s2p[21] == s2p[1]
+    seq2 = seq.copy()
+    seq2[seq2 == 64] = -1
+    s2p2, w2, _ = compress_patterns(seq2)
+    np.testing.assert_array_equal(s2p, s2p2)
+    # empty alignment
+    s2p, w, first = compress_patterns(np.zeros((4, 0), dtype=np.int32))
+    assert len(w) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# input producers against the reference's fixtures
+# ---------------------------------------------------------------------------------------------
+def _lysozyme():
+    from crabml_amd.io import Alignment
+    return Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"))
+
+
+@pytest.mark.parametrize("model", LYSOZYME_MODELS)
+def test_models_reproduce_reference_q_matrices(model):
+    import json
+    from crabml_amd import models
+    c = load_case(f"lysozyme_{model}")
+    aln = _lysozyme()
+    pi = models.compute_codon_frequencies_f3x4(aln)
+    np.testing.assert_allclose(pi, c["pi"], rtol=1e-14)
+    kw = json.loads(str(c["params_json"]))
+    cls = {"m0": "M0CodonModel", "m1a": "M1aCodonModel", "m2a": "M2aCodonModel", "m3": "M3CodonModel", "m4": "M4CodonModel",
+           "m5": "M5CodonModel", "m6": "M6CodonModel", "m7": "M7CodonModel", "m8": "M8CodonModel", "m8a": "M8aCodonModel",
+           "m9": "M9CodonModel"}[model]
+    m = getattr(models, cls)(pi=pi, **kw)
+    if model == "m0":
+        Q, props = [m.get_Q_matrix()], [1.0]
+    else:
+        Q = m.get_Q_matrices()
+        props, omegas = m.get_site_classes()
+        np.testing.assert_allclose(omegas, c["omegas"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(props, c["proportions"], rtol=1e-14)
+    np.testing.assert_allclose(np.stack(Q), c["Q"], rtol=1e-12, atol=1e-18)
+
+
+def test_adapter_reproduces_reference_boundary_inputs():
+    """Tree renumbering and sequence packing (core/likelihood_rust.py:98-158) without touching the device."""
+    from crabml_amd.io import Alignment, Tree
+    from crabml_amd.likelihood_rust import RustLikelihoodCalculator
+    cases = [("lysozyme_m8", _lysozyme()),
+             ("hiv_m8a", Alignment.from_fasta(os.path.join(DATA, "HIVenvSweden.fasta"))),
+             ("lysin_m2a_gaps", Alignment.from_fasta(os.path.join(DATA, "lysin.fasta"))),
+             ("lysozymeLarge_modelA", Alignment.from_phylip(os.path.join(DATA, "lysozymeLarge_clean.nuc")))]
+    for name, aln in cases:
+        c = load_case(name)
+        tree = Tree.from_newick(str(c["newick"]))
+        calc = object.__new__(RustLikelihoodCalculator)
+        calc.alignment, calc.tree = aln, tree
+        calc.leaf_to_seq_idx = {n: i for i, n in enumerate(aln.names)}
+        calc._prepare_tree_structure()
+        calc._prepare_sequences()
+        assert [-1 if p is None else p for _, p in calc.tree_structure] == list(c["parent"]), name
+        np.testing.assert_allclose(calc.branch_lengths_template, c["branch_lengths"], rtol=0, atol=0)
+        np.testing.assert_array_equal(calc.sequences, c["sequences"])
+        assert calc.leaf_names_ordered == [str(x) for x in c["leaf_names"]]
+        assert calc.sequences.dtype == np.int32 and calc.sequences.flags.c_contiguous
+        if name == "lysozymeLarge_modelA":
+            np.testing.assert_array_equal(calc.renumber_branch_labels(), c["branch_labels"])
+
+
+def test_model_a_inputs_reproduce_reference():
+    from crabml_amd import models
+    c = load_case("lysozymeLarge_modelA")
+    ma = models.BranchSiteModelA(c["pi"], c["branch_labels"].astype(int))
+    np.testing.assert_allclose(ma.compute_site_class_frequencies(float(c["p0"]), float(c["p1"])), c["site_class_freqs"], rtol=1e-14)
+    qb, qf = ma.compute_qfactors(float(c["kappa"]), float(c["p0"]), float(c["p1"]), float(c["omega0"]), float(c["omega2"]))
+    np.testing.assert_allclose([qb, qf], c["qfactors"], rtol=1e-13)
+    np.testing.assert_allclose(np.stack(ma.unnormalised_Qs(float(c["kappa"]), float(c["omega0"]), float(c["omega2"]))), c["Q"],
+                               rtol=1e-13, atol=1e-18)
+    with pytest.raises(ValueError):
+        ma.compute_site_class_frequencies(0.6, 0.5)
+
+
+def test_newick_reader():
+    from crabml_amd.io import Tree
+    t = Tree.from_newick(open(os.path.join(DATA, "lysozymeLarge.trees")).read())
+    assert t.n_leaves == 19 and t.n_nodes == 34 and sum(t.branch_labels()) == 1
+    assert max(len(ch) for ch in t.children) == 3  # internal multifurcation + trifurcating root
+    t2 = Tree.from_newick(t.to_newick())
+    np.testing.assert_array_equal(t.parent, t2.parent)
+    np.testing.assert_allclose(t.branch_length, t2.branch_length)
+    with pytest.raises(ValueError):
+        Tree.from_newick("((A,B),C)")
+    t3 = Tree.from_newick("((1,2) #1, ((3,4), 5), (6,7) );        / * table 1C&G */")
+    assert t3.n_leaves == 7 and t3.branch_labels().count(1) == 1
+
+
+def test_codon_encoding():
+    from crabml_amd.io import CODONS, encode_codon_string
+    assert len(CODONS) == 61 and CODONS[0] == "TTT" and CODONS[-1] == "GGG" and "TAA" not in CODONS
+    np.testing.assert_array_equal(encode_codon_string("TTTTAA---GGGNNNATG"), [0, -1, 64, 60, -1, CODONS.index("ATG")])
+
+
+def test_c_and_python_q_builders_agree():
+    from crabml_amd import crabml_rust as shim
+    from crabml_amd.models import build_codon_Q_matrix
+    rng = np.random.default_rng(5)
+    pi = rng.dirichlet(np.ones(61))
+    for kappa, omega, nf in [(2.0, 0.5, None), (4.3, 1.7, 1.0), (1.0, 0.0, None), (3.0, 2.0, 0.37)]:
+        np.testing.assert_allclose(shim.build_codon_q_matrix_py(kappa, omega, pi, nf), build_codon_Q_matrix(kappa, omega, pi, nf),
+                                   rtol=1e-13, atol=1e-17)
+    with pytest.raises(ValueError):
+        shim.build_codon_q_matrix_py(2.0, 0.5, pi[:60])
