@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Benchmark of the likelihood hot path: BASELINE.json configs[1], M8 (10 beta + 1 omega>1 class) on a
+synthetic 100-taxon x 10 000-codon alignment per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one complete lnL evaluation through the C ABI (crab_eval_site_classes): host eigendecomposition
+of the 11 rate matrices, upload, batched P(t), pruning, mixture, 8-byte result back.  The alignment is
+already resident in HBM (uploaded once by crab_set_alignment, outside the timed region).
+Multi-GPU is weak scaling: rank r owns an independent 10 000-codon block evolved on the same tree, i.e.
+the site patterns of an N x 10 000-codon alignment are sharded over N GPUs; every step ends with the
+rank-ordered sum of the N partial lnL values over RCCL.
+
+Rank 0 prints ONE JSON line.  `value` is pattern x branch x class conditional-likelihood updates per
+second over all GPUs (the unit BASELINE.md uses: 21.67 M per evaluation of this workload), lnL
+evaluations per second are reported beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_UPDATE = 2 * 61 * 61          # one dense CL update, 61 states, padding never counted
+FP64_MFMA_PEAK_TFLOPS = 78.6           # MI355X FP64 matrix peak (AMD CDNA4 datasheet; the microarch guide lists no f64 row)
+N_TAXA, N_SITES, SEED = 100, 10000, 2
+
+
+def cpu_baseline(case, sample_sites=2000, reps=2):
+    """The oracle (CPU restatement of the Rust path, reference mode) on a bounded sample of the same workload,
+    one thread per site class like the reference's Rayon loop (likelihood.rs:267)."""
+    from oracle import oracle as orc
+    codes = np.ascontiguousarray(case.codes[:, :sample_sites])
+    K = len(case.proportions)
+    threads = min(K, os.cpu_count() or 1, 16)
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        orc.compute_site_class_log_likelihood(list(case.Q), case.proportions, case.pi, case.tree_structure, case.branch_lengths,
+                                              None, codes, case.leaf_node_ids, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+    updates = sample_sites * (case.n_nodes - 1) * K
+    return {"value": updates / best, "unit": "CL updates/s", "cores": threads, "kind": "port",
+            "lnl_evals_per_s": 1.0 / (best * case.n_sites / sample_sites),
+            "sample": f"{sample_sites} of {case.n_sites} codons, all {K} classes, all {case.n_nodes - 1} branches dense "
+                      f"(unscaled reference mode), best of {reps}; evals/s scaled linearly to {case.n_sites} codons"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    from crabml_amd import synth
+    from crabml_amd.dist import ordered_sum
+    from crabml_amd.engine import Engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    case = synth.make_case("M8", N_TAXA, N_SITES, seed=SEED, block=rank)
+    eng = Engine(local_rank)
+    eng.set_tree(case.parent, case.leaf_node_ids)
+    eng.set_alignment(case.codes, n_states=61)
+    K = len(case.proportions)
+    n_branches = case.n_nodes - 1
+
+    def step():
+        partial = eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths)
+        return ordered_sum(partial)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lnL = step()
+    prune_ms, device_ms, eigen_ms = [], [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnL = step()
+        d, p, e = eng.last_timing()
+        device_ms.append(d)
+        prune_ms.append(p)
+        eigen_ms.append(e)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    dense, gather = eng.last_work()
+    n_pat = eng.n_patterns
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        updates_per_eval = world * N_SITES * n_branches * K           # reference units: every site, every branch, every class
+        kernel_ms = float(np.mean(prune_ms))
+        achieved = dense * FLOP_PER_UPDATE / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "pattern x branch CL updates/sec, M8 (lnL evals/sec alongside)",
+            "value": updates_per_eval * args.steps / elapsed,
+            "unit": "CL updates/s",
+            "lnl_evals_per_s": args.steps / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: M8 (10 beta + 1 omega>1 class), 100 taxa x 10000 codons per GPU, "
+                                   "random bushy tree, tree length %.2f subst/codon, 1%% gap codons" % case.tree_length,
+                       "taxa": N_TAXA, "codons_per_gpu": N_SITES, "patterns_per_gpu": n_pat, "classes": K,
+                       "branches": n_branches, "sharding": f"patterns over {world} GPU(s)", "lnL": lnL},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "prune_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_flop_per_launch": dense * FLOP_PER_UPDATE,
+                         "dense_updates_per_launch": dense, "gathered_leaf_updates_per_launch": gather},
+            "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms,
+                             "host_eigen": float(np.mean(eigen_ms))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(case)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

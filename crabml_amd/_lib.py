@@ -40,6 +40,7 @@ SIGNATURES = {
     "crab_eval_branch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, C.c_uint, dp, dp]),
     "crab_last_timing": (C.c_int, [vp, dp, dp, dp]),
     "crab_last_work": (C.c_int, [vp, lp, lp]),
+    "crab_export_transition_matrices": (C.c_int, [vp, C.c_int, dp]),
     "crab_matrix_exponential": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_double, dp]),
     "crab_build_codon_q_matrix": (C.c_int, [C.c_double, C.c_double, dp, C.c_int, C.c_double, dp]),
     "crab_compile_tree": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -140,6 +140,8 @@ struct crab_engine : TreeProgram {
     PinBuf<int32_t> h_int;
 
     // ---- last-eval facts ----
+    std::vector<int32_t> last_pidx;  // [K][n_nodes] of the last evaluation
+    int last_K = 0, last_M = 0;
     double last_device_ms = 0, last_prune_ms = 0, last_eigen_ms = 0;
     int64_t last_dense = 0, last_gather = 0;
 
@@ -595,6 +597,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_device_ms = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev_k0, e->ev_k1));
     e->last_prune_ms = ms;
+    e->last_pidx = pl.pidx;
+    e->last_K = pl.K;
+    e->last_M = pl.M;
     e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
     e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
 
@@ -824,6 +829,24 @@ int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kern
     if (prune_kernel_ms) *prune_kernel_ms = e->last_prune_ms;
     if (host_eigen_ms) *host_eigen_ms = e->last_eigen_ms;
     return CRAB_OK;
+}
+
+int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        if (!P_out || k < 0 || k >= e->last_K || e->last_M <= 0) fail(CRAB_ERR_STATE, "no evaluation to export from, or class out of range");
+        const int n = e->n_states, nn = e->n_nodes;
+        HIP_CHECK(hipSetDevice(e->device));
+        std::vector<double> img((size_t)e->last_M * P_ELEMS);
+        HIP_CHECK(hipMemcpy(img.data(), e->d_P.p, img.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int v = 0; v < nn; ++v) {
+            const double *Pm = img.data() + (size_t)e->last_pidx[(size_t)k * nn + v] * P_ELEMS;
+            double *out = P_out + (size_t)v * n * n;
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] = Pm[p_frag_index(i, j)];
+        }
+    });
 }
 
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)

@@ -165,6 +165,12 @@ class Engine:
         self._check(self._lib.crab_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def export_transition_matrices(self, k=0):
+        """[n_nodes, n, n] transition matrices the last evaluation built on the device for class k."""
+        out = np.empty((self.n_nodes, self.n_states, self.n_states))
+        self._check(self._lib.crab_export_transition_matrices(self._h, int(k), out.ctypes.data_as(L.dp)))
+        return out
+
     def last_work(self):
         """(dense MFMA updates, gathered leaf updates) of the last evaluation, in pattern x branch x class units."""
         a, b = C.c_int64(), C.c_int64()

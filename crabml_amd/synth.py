@@ -89,9 +89,13 @@ def evolve(parent, bl, pi, site_Q_of_node, site_class, n_sites, rng, gap_fractio
     return np.ascontiguousarray(codes)
 
 
-def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: float | None = None, gap_fraction=0.01):
+def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: float | None = None, gap_fraction=0.01,
+              block: int = 0):
     """model in {"M0", "M7", "M8", "ModelA", "free-ratio"}.  Returns a namespace with everything the
-    boundary needs (parent, leaf_node_ids, tree_structure, branch_lengths, codes, pi, Q, proportions, ...)."""
+    boundary needs (parent, leaf_node_ids, tree_structure, branch_lengths, codes, pi, Q, proportions, ...).
+
+    ``seed`` fixes the tree and the model parameters; ``block`` selects an independent block of ``n_sites``
+    columns evolved on that same tree (rank r of a multi-GPU run evaluates block r: weak scaling)."""
     rng = np.random.default_rng(seed)
     n_branches = 2 * n_taxa - 3
     if mean_branch is None:
@@ -100,6 +104,8 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
     n_nodes = len(parent)
     pi = rng.dirichlet(5.0 * np.ones(61))
     kappa = 2.5
+    tree_rng = rng
+    rng = np.random.default_rng([seed, 7919 + block])  # sequences: independent of the tree stream, one per block
     case = SimpleNamespace(model=model, n_taxa=n_taxa, n_sites=n_sites, seed=seed, parent=parent, branch_lengths=bl, pi=pi,
                            kappa=kappa, n_nodes=n_nodes, leaf_node_ids=np.arange(n_taxa, dtype=np.int32),
                            tree_structure=[(v, None if parent[v] < 0 else int(parent[v])) for v in range(n_nodes)],
@@ -121,7 +127,7 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
         p0, p1, w0, w2 = 0.5, 0.3, 0.1, 3.0
         labels = np.zeros(n_nodes - 1, dtype=np.uint8)
         internals = np.arange(n_taxa, n_nodes - 1)
-        fg_root = int(rng.choice(internals)) if len(internals) else 0
+        fg_root = int(tree_rng.choice(internals)) if len(internals) else 0
         below = np.zeros(n_nodes, dtype=bool)
         below[fg_root] = True
         for v in range(n_nodes - 2, -1, -1):
@@ -147,7 +153,7 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
         case.omega0, case.omega2 = w0, w2
         case.codes = evolve(parent, bl, pi, q_of, site_class, n_sites, rng, gap_fraction)
     elif model == "free-ratio":
-        omegas = np.exp(rng.normal(np.log(0.3), 0.5, size=n_nodes - 1))
+        omegas = np.exp(tree_rng.normal(np.log(0.3), 0.5, size=n_nodes - 1))
         bm = models.CodonBranchModel(pi, np.zeros(n_nodes, dtype=int), free_ratio=True, n_nodes=n_nodes)
         Qn = bm.get_Q_matrices(kappa, omegas)
         case.Q_per_node, case.omegas = Qn, omegas

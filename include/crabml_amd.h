@@ -110,6 +110,12 @@ int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kern
  * (pattern x branch x class) updates executed as MFMA products, and of leaf-edge updates done as gathers. */
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates);
 
+/* Copies out the transition matrices the last crab_eval_* built on the device for class k:
+ * P_out[v][i][j] = P(branch above node v)[i][j], shape [n_nodes][n][n].  Lets a caller (and the parity
+ * tests) check kernel 1 and kernel 2 separately.  Replaces nothing in the reference: its P matrices
+ * (matrix.rs:108-112) never leave the call. */
+int crab_export_transition_matrices(crab_engine *e, int k, double *P_out);
+
 /* ---- stateless utilities ----------------------------------------------------- */
 /* matrix_exponential (lib.rs:61-79 -> matrix.rs:31-102): P = exp(Q t), computed on the device
  * with the same batched kernel the evaluations use.  P_out: [n][n]. */

@@ -637,6 +637,32 @@ int orc_branch_site_log_likelihood(int n, const double *Q3, double qf_back, doub
     return rc;
 }
 
+/* Pruning alone, from caller-supplied transition matrices: P[K][n_nodes][n][n] -> out_f[k*S+s] (and the
+ * power-of-two exponents out_e when scaled).  naive selects the branch-site calculator's loop.  This is
+ * compute_site_likelihoods (likelihood.rs:200-246) minus its expm_multiple call; the parity tests feed it
+ * the matrices exported from the device so that kernel 2 is checked independently of kernel 1. */
+int orc_site_likelihoods_from_p(int K, int n, const double *P, const double *pi, int n_nodes, const int32_t *node_ids,
+                                const int32_t *parents, const int32_t *seq, int n_leaves, int S,
+                                const int32_t *leaf_node_ids, int naive, int scaled, int threads, double *out_f,
+                                int32_t *out_e)
+{
+    orc_tree t;
+    int rc = tree_build(&t, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+    if (rc != ORC_OK) { tree_free(&t); return rc; }
+    int rc_all = ORC_OK;
+#ifdef _OPENMP
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+    for (int k = 0; k < K; k++) {
+        int r = prune(&t, S, n, P + (size_t)k * n_nodes * n * n, pi, seq, naive, scaled, out_f + (size_t)k * S,
+                      out_e + (size_t)k * S);
+        if (r != ORC_OK) rc_all = r;
+    }
+    tree_free(&t);
+    return rc_all;
+}
+
 /* ------------------------------------------------------------------ */
 /* build_codon_q_matrix (rust/src/qmatrix.rs:22-80) over the codon graph  */
 /* of rust/src/codon.rs:63-87,167-220 (PAML order, T C A G, stops removed) */

@@ -171,6 +171,27 @@ def compute_log_likelihood_branch(sequences, parent_indices, leaf_node_ids, Q_ma
     return (lnL.value, site) if return_sites else lnL.value
 
 
+def site_lnf_from_transition_matrices(P, pi, tree_structure, sequences, leaf_node_ids, naive=False, threads=None):
+    """ln f_{k,s} (no clamp; evaluated with rescaling so it never underflows) from P[K][n_nodes][n][n]."""
+    P_, Pp = _d(P)
+    if P_.ndim == 3:
+        P_ = P_[None]
+    pi_, pp = _d(pi)
+    (ids, idp), (par, parp) = _tree_args(tree_structure)
+    seq, sp = _i(sequences)
+    leaf, lp = _i(leaf_node_ids)
+    K, S = P_.shape[0], seq.shape[1]
+    threads = min(K, os.cpu_count() or 1) if threads is None else threads
+    f = np.empty((K, S))
+    e = np.empty((K, S), dtype=np.int32)
+    _check(lib().orc_site_likelihoods_from_p(K, len(pi_), P_.ctypes.data_as(_dp), pp, len(ids), idp, parp, sp, len(leaf), S, lp,
+                                             int(naive), 1, int(threads), f.ctypes.data_as(_dp), e.ctypes.data_as(_ip)),
+           "site_lnf_from_transition_matrices")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        # f <= 0 (a class that forbids the data, up to rounding noise of either sign) is reported as -inf
+        return np.where(f > 0, np.log(np.where(f > 0, f, 1.0)) + e * np.log(2.0), -np.inf).T  # [S, K]
+
+
 def build_codon_q_matrix_py(kappa, omega, pi, normalization_factor=None):
     pi_, pp = _d(pi)
     out = np.empty((61, 61))
