@@ -67,6 +67,7 @@ struct PruneArgs {
     double *out_f;            // [K][n_pat_pad]  scaled site likelihood per class
     int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
     int32_t first_gemm_node;  // node of the first GEMM op (-1 if none)
+    int32_t debug;            // timing ablations (CRAB_DEBUG_SKIP); 0 in production
 };
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();

@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
 
             if (op.kind == OP_GEMM) {
                 // the matrix for this edge was requested one GEMM ago
+                if (!(a.debug & 8)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (op.arg >= 0) dma_matrix(a.P + (size_t)pidx[op.arg] * P_ELEMS, smem + (buf ^ 1) * 32768, wave, lane);
+                }
                 const double *A = (const double *)(smem + buf * 32768) + lane;
                 buf ^= 1;
 
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+                if (!(a.debug & 4))
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -195,6 +198,14 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
                 // fragment-order image in global memory (L2-resident, shared by every workgroup)
                 const double *Pm = a.P + (size_t)pidx[op.node] * P_ELEMS + g;
                 const uint8_t *row = a.codes + (size_t)op.arg * a.n_pat_pad + pat0;
+                if (a.debug & 1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        et[nt] = 0;
+#pragma unroll
+                        for (int idx = 0; idx < 16; ++idx) t[nt][idx] = 0.5;
+                    }
+                } else
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int code = row[nt * 16];
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
                     for (int idx = 0; idx < 16; ++idx) t[nt][idx] *= prod[nt][idx];
                 }
             }
-            if (op.flags & F_POP_MUL) {
+            if ((op.flags & F_POP_MUL) && !(a.debug & 2)) {
                 const double *sp = my_stack + (size_t)op.slot * slot_doubles;
                 const int32_t *se = my_stack_e + (size_t)op.slot * (NT * 64);
 #pragma unroll
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) normalise(prod[nt], eprod[nt]);
             }
-            if (op.flags & F_PUSH) {
+            if ((op.flags & F_PUSH) && !(a.debug & 2)) {
                 double *sp = my_stack + (size_t)op.slot * slot_doubles;
                 int32_t *se = my_stack_e + (size_t)op.slot * (NT * 64);
 #pragma unroll
@@ -319,9 +330,11 @@ int prune_grid_size(int64_t n_work)
 size_t prune_stack_doubles(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 16 * 64; }
 size_t prune_stack_ints(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 64; }
 
-void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
+void launch_prune(const PruneArgs &a_in, int grid, hipStream_t stream)
 {
-    if (grid <= 0 || a.n_ops <= 0) return;
+    if (grid <= 0 || a_in.n_ops <= 0) return;
+    PruneArgs a = a_in;
+    if (const char *s = std::getenv("CRAB_DEBUG_SKIP")) a.debug = std::atoi(s);  // timing ablations only: wrong results
     const int nt = chosen_nt();
     const long long n_tiles = a.n_pat_pad / (64 * nt);
     const size_t lds = 2 * 32768;
