@@ -844,7 +844,7 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
             const double *Pm = img.data() + (size_t)e->last_pidx[(size_t)k * nn + v] * P_ELEMS;
             double *out = P_out + (size_t)v * n * n;
             for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] = Pm[p_frag_index(i, j)];
+                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] = Pm[p_operand_index(i, j)];
         }
     });
 }
@@ -935,7 +935,7 @@ int crab_matrix_exponential(int device, int n, const double *Q, const double *pi
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpy(Pf.data(), d_P.p, P_ELEMS * sizeof(double), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) P_out[(size_t)i * n + j] = Pf[p_frag_index(i, j)];
+            for (int j = 0; j < n; ++j) P_out[(size_t)i * n + j] = Pf[p_gather_index(i, j)];
     });
 }
 

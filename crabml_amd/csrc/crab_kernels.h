@@ -9,20 +9,33 @@
 namespace crab {
 
 // ---- layouts ------------------------------------------------------------------------------
-// A transition matrix P (64 x 64 padded, P[i][j] = Pr(j at child | i at parent)) is stored in the
-// operand order of v_mfma_f64_16x16x4_f64 with P as the A operand ("fragment order"):
-//     element (i, j) lives at  ((i>>4)*16 + (j>>2))*64 + (i&15) + 16*(j&3)
-// i.e. fragment (mt = i/16, s = j/4) is 64 consecutive doubles, lane l of a wave holding
-// A[m = l&15][k = l>>4].  Column n_states (61) holds the row sums sum_j P[i][j] (used for missing
-// data); rows/columns >= n_states are otherwise zero.
-constexpr int P_ELEMS = NS * NS;  // doubles per matrix (32 KiB)
+// A transition matrix P (64 x 64 padded, P[i][j] = Pr(j at child | i at parent)) is kept twice, 64 KiB in all:
+//
+//  operand image (doubles [0, 4096)): the A-operand order of v_mfma_f64_4x4x4_4b_f64.  P is cut into 4x4
+//     tiles (I = i/4, s = j/4); a lane l of the wave supplies A[i' = l&3][k = l>>4] of its tile (the same
+//     value in all four 4-lane blocks), so a tile is 16 doubles ordered (k*4 + i').  Tiles s and s+1 are
+//     interleaved so that one 16-byte LDS read feeds two MFMAs:
+//         element (i, j) lives at  (((i>>2)*8 + (j>>3))*16 + (j&3)*4 + (i&3))*2 + ((j>>2)&1)
+//  gather image (doubles [4096, 8192)): column j of P with the 16 states one lane owns contiguous:
+//         element (i, j) lives at  4096 + (j*4 + (i&3))*16 + (i>>2)
+//     so a leaf edge is eight 16-byte loads per lane.
+//
+// Column n_states (61) holds the row sums sum_j P[i][j] (used for missing data); rows and columns
+// >= n_states are otherwise zero.
+constexpr int P_IMAGE = NS * NS;       // doubles per image (32 KiB)
+constexpr int P_ELEMS = 2 * P_IMAGE;   // doubles per matrix, both images
 
-__host__ __device__ inline int p_frag_index(int i, int j) { return ((i >> 4) * 16 + (j >> 2)) * 64 + (i & 15) + 16 * (j & 3); }
+__host__ __device__ inline int p_operand_index(int i, int j)
+{
+    return ((((i >> 2) * 8 + (j >> 3)) * 16) + (j & 3) * 4 + (i & 3)) * 2 + ((j >> 2) & 1);
+}
+__host__ __device__ inline int p_gather_index(int i, int j) { return P_IMAGE + (j * 4 + (i & 3)) * 16 + (i >> 2); }
 
 // Conditional likelihoods never touch HBM.  Inside the pruning kernel a wave holds a
 // [64 states x 16 patterns] tile per pattern group: lane l owns pattern (l&15) and the 16 states
-// 4*idx + (l>>4), idx = 0..15 -- the C/D layout of the MFMA, which is also its B-operand layout,
-// so a parent's product consumes the child's tile straight from registers.
+// 4*idx + (l>>4), idx = 0..15.  That is the C/D layout of the 4x4x4 MFMA (D[blk][i][j] in lane
+// 16*i + 4*blk + j) and also its B-operand layout (B[blk][k][j] in lane 16*k + 4*blk + j), so a parent's
+// product consumes the child's tile straight from registers, register idx being k-step idx.
 
 // ---- tree program ---------------------------------------------------------------------------
 enum : int32_t { OP_GEMM = 0, OP_LEAF = 1, OP_CONST = 2 };

@@ -8,7 +8,10 @@
 //                    power-of-two rescaling are fused; P matrices stream through LDS by LDS-DMA
 //   mix_kernel       per-pattern class mixture, log, pattern-weighted deterministic sum
 //
-// Written for wave64 / v_mfma_f64_16x16x4_f64 only.  No other architecture is supported.
+// fp64 MFMA shape: the pruning products use v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X
+// (scripts/micro/): it sustains 64-72 TFLOP/s against 35-49 TFLOP/s for v_mfma_f64_16x16x4_f64, and its
+// D lane map equals its B lane map, so products chain through registers.
+// Written for gfx950 wave64 only.  No other architecture is supported.
 #include "crab_kernels.h"
 
 #include <cmath>
@@ -26,10 +29,10 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // =============================================================================================
 // One workgroup (4 waves) per matrix; wave w produces rows i in [16w, 16w+16) of P.
 // It computes the transposed tiles D^T[j][i] = sum_k Uinv[k][j] * (U[i][k] e^{lam_k t}) with
-// A = Uinv^T (M index = j), B = (U diag)^T (N index = i): with the f64 C/D map
-// (col = lane&15, row = (lane>>4) + 4*reg) lane l / register r of tile jt then holds
-// P[16w + (l&15)][16jt + 4r + (l>>4)], which is exactly element l of fragment (mt = w, s = 4jt + r)
-// of the fragment-order image -- every store is a contiguous 512-byte row.
+// A = Uinv^T (M index = j), B = (U diag)^T (N index = i) on v_mfma_f64_16x16x4_f64: with the f64 C/D map
+// (col = lane&15, row = (lane>>4) + 4*reg) lane l / register r of tile jt holds
+// P[16w + (l&15)][16jt + 4r + (l>>4)], stored into both images of crab_kernels.h.  (This kernel is ~1 % of an
+// evaluation; the stores are 8-byte scatters.)
 __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__ eig, const int32_t *__restrict__ eig_id,
                                                       const double *__restrict__ t_eff, double *__restrict__ P, int n_states)
 {
@@ -65,14 +68,17 @@ __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__
     rs += __shfl_xor(rs, 32);
     // column n_states (a padding column, zero so far) receives the row sum
     const int ns_jt = n_states >> 4, ns_r = (n_states >> 2) & 3, ns_g = n_states & 3;
-    double *out = P + (size_t)m * P_ELEMS + (size_t)mt * 16 * 64 + lane;
+    double *out = P + (size_t)m * P_ELEMS;
+    const int i = 16 * mt + c;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double v = acc[jt][r];
             if (jt == ns_jt && r == ns_r && g == ns_g) v = rs;
-            out[(4 * jt + r) * 64] = v;
+            const int j = 16 * jt + 4 * r + g;
+            out[p_operand_index(i, j)] = v;
+            out[p_gather_index(i, j)] = v;
         }
 }
 
@@ -110,7 +116,7 @@ __device__ __forceinline__ void normalise(double (&v)[16], int &e)
     }
 }
 
-// Issue the LDS-DMA of one 32 KiB fragment-order matrix: each of the 4 waves moves 8 x 1 KiB.
+// Issue the LDS-DMA of one 32 KiB operand image: each of the 4 waves moves 8 x 1 KiB.
 __device__ __forceinline__ void dma_matrix(const double *Pm, char *lds_buf, int wave, int lane)
 {
     const char *gsrc = (const char *)Pm + wave * 8192 + lane * 16;
@@ -120,10 +126,12 @@ __device__ __forceinline__ void dma_matrix(const double *Pm, char *lds_buf, int 
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + i * 1024), LDS_PTR(ldst + i * 1024), 16, 0, 0);
 }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 template <int NT>
-__global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_tiles)
+__global__ __launch_bounds__(256, 4) void prune_kernel(PruneArgs a, long long n_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // two 32 KiB matrix buffers
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // one 32 KiB operand image
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,6 +141,8 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
     const size_t slot_doubles = (size_t)NT * 16 * 64;
     double *my_stack = a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_doubles + lane;
     int32_t *my_stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;
+    // this lane's A operand inside a tile pair: element (k = g, i' = lane&3), two consecutive doubles
+    const v2d *A2 = (const v2d *)smem + (g * 4 + (lane & 3));
 
     for (long long w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int cls = (int)(w / n_tiles);
@@ -150,9 +160,8 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
             for (int i = 0; i < 16; ++i) cur[nt][i] = prod[nt][i] = 0.0;
         }
 
-        int buf = 0;
         __syncthreads();  // every wave is done reading LDS for the previous work item
-        if (a.first_gemm_node >= 0) dma_matrix(a.P + (size_t)pidx[a.first_gemm_node] * P_ELEMS, smem, wave, lane);
+        if (a.first_gemm_node >= 0 && !(a.debug & 8)) dma_matrix(a.P + (size_t)pidx[a.first_gemm_node] * P_ELEMS, smem, wave, lane);
 
         for (int ip = 0; ip < a.n_ops; ++ip) {
             const TreeOp op = a.ops[ip];
@@ -160,43 +169,46 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
             int et[NT];
 
             if (op.kind == OP_GEMM) {
-                // the matrix for this edge was requested one GEMM ago
+                // the operand image of this edge was requested right after the previous product
                 if (!(a.debug & 8)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (op.arg >= 0) dma_matrix(a.P + (size_t)pidx[op.arg] * P_ELEMS, smem + (buf ^ 1) * 32768, wave, lane);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
                 }
-                const double *A = (const double *)(smem + buf * 32768) + lane;
-                buf ^= 1;
-
-                v4d acc[NT][4];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = (v4d){0.0, 0.0, 0.0, 0.0};
-                if (!(a.debug & 4))
+                    for (int i = 0; i < 16; ++i) t[nt][i] = 0.0;
+                if (!(a.debug & 4)) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
+                    for (int sp = 0; sp < 8; ++sp) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const double av = A[(mt * 16 + s) * 64];
+                        for (int ic = 0; ic < 4; ++ic) {
+                            v2d av[4];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, cur[nt][s], acc[nt][mt], 0, 0, 0);
+                            for (int q = 0; q < 4; ++q) av[q] = A2[((ic * 4 + q) * 8 + sp) * 16];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    t[nt][ic * 4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q][0], cur[nt][2 * sp], t[nt][ic * 4 + q], 0, 0, 0);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    t[nt][ic * 4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q][1], cur[nt][2 * sp + 1], t[nt][ic * 4 + q], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    et[nt] = ecur[nt];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) t[nt][4 * mt + r] = acc[nt][mt][r];
+                for (int nt = 0; nt < NT; ++nt) et[nt] = ecur[nt];
+                if (!(a.debug & 8)) {
+                    __syncthreads();  // all four waves have read the image: the buffer is free for the next edge
+                    if (op.arg >= 0) dma_matrix(a.P + (size_t)pidx[op.arg] * P_ELEMS, smem, wave, lane);
                 }
             } else if (op.kind == OP_LEAF) {
-                // P[i][code] for the 16 states i = 4*idx + g of this lane: a column gather from the
-                // fragment-order image in global memory (L2-resident, shared by every workgroup)
-                const double *Pm = a.P + (size_t)pidx[op.node] * P_ELEMS + g;
+                // P[i][code] for the 16 states i = 4*idx + g of this lane: 128 contiguous bytes of the gather
+                // image in global memory (L2-resident, shared by every workgroup walking this class)
+                const v2d *G2 = (const v2d *)(a.P + (size_t)pidx[op.node] * P_ELEMS + P_IMAGE) + g * 8;
                 const uint8_t *row = a.codes + (size_t)op.arg * a.n_pat_pad + pat0;
                 if (a.debug & 1) {
 #pragma unroll
@@ -205,14 +217,19 @@ __global__ __launch_bounds__(256) void prune_kernel(PruneArgs a, long long n_til
 #pragma unroll
                         for (int idx = 0; idx < 16; ++idx) t[nt][idx] = 0.5;
                     }
-                } else
+                } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int code = row[nt * 16];
-                    const double *col = Pm + (code >> 2) * 64 + (code & 3) * 16;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int code = row[nt * 16];
+                        const v2d *col = G2 + code * 32;
 #pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) t[nt][idx] = col[(idx >> 2) * 1024 + (idx & 3) * 4];
-                    et[nt] = 0;
+                        for (int q = 0; q < 8; ++q) {
+                            const v2d v = col[q];
+                            t[nt][2 * q] = v[0];
+                            t[nt][2 * q + 1] = v[1];
+                        }
+                        et[nt] = 0;
+                    }
                 }
             } else {  // OP_CONST: childless non-leaf node
                 const double v = op.arg ? 1.0 : 0.0;
@@ -293,7 +310,7 @@ static int g_nt = 0;
 static int chosen_nt()
 {
     if (g_nt == 0) {
-        g_nt = 2;
+        g_nt = 1;
         if (const char *s = std::getenv("CRAB_NT")) {
             const int v = std::atoi(s);
             if (v == 1 || v == 2) g_nt = v;
@@ -301,14 +318,19 @@ static int chosen_nt()
     }
     return g_nt;
 }
+constexpr size_t PRUNE_LDS_BYTES = P_IMAGE * sizeof(double);
 static int g_blocks_per_cu = 0;
 static int blocks_per_cu()
 {
     if (g_blocks_per_cu == 0) {
-        g_blocks_per_cu = 2;
+        int occ = 0;
+        const hipError_t err = chosen_nt() == 1
+                                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<1>, 256, PRUNE_LDS_BYTES)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<2>, 256, PRUNE_LDS_BYTES);
+        g_blocks_per_cu = (err == hipSuccess && occ >= 1) ? (occ > 4 ? 4 : occ) : 1;
         if (const char *s = std::getenv("CRAB_BLOCKS_PER_CU")) {
             const int v = std::atoi(s);
-            if (v >= 1 && v <= 2) g_blocks_per_cu = v;
+            if (v >= 1 && v <= g_blocks_per_cu) g_blocks_per_cu = v;
         }
     }
     return g_blocks_per_cu;
@@ -337,7 +359,7 @@ void launch_prune(const PruneArgs &a_in, int grid, hipStream_t stream)
     if (const char *s = std::getenv("CRAB_DEBUG_SKIP")) a.debug = std::atoi(s);  // timing ablations only: wrong results
     const int nt = chosen_nt();
     const long long n_tiles = a.n_pat_pad / (64 * nt);
-    const size_t lds = 2 * 32768;
+    const size_t lds = PRUNE_LDS_BYTES;
     if (nt == 1)
         hipLaunchKernelGGL(prune_kernel<1>, dim3(grid), dim3(256), lds, stream, a, n_tiles);
     else
