@@ -110,7 +110,7 @@ struct TreeProgram {
     std::vector<int> parent, child_start, child, leaf_row;
     std::vector<char> in_leaf_set, reachable;
     std::vector<TreeOp> ops;
-    int max_depth = 0, first_gemm_node = -1;
+    int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1;
     int64_t n_gemm_edges = 0, n_leaf_edges = 0;
 };
 
@@ -122,7 +122,7 @@ struct crab_engine : TreeProgram {
 
     // ---- tree ----
     bool have_tree = false;
-    bool ops_uploaded = false;
+    std::vector<DevOp> dev_ops;  // [K][n_ops_pad] programs as last uploaded
 
     // ---- alignment ----
     bool have_aln = false;
@@ -132,10 +132,10 @@ struct crab_engine : TreeProgram {
     std::vector<double> weights;       // per local pattern
 
     // ---- device state ----
-    DevBuf<TreeOp> d_ops;
+    DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_eig, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_eig_id, d_pidx, d_stack_e, d_e;
+    DevBuf<int32_t> d_eig_id, d_stack_e, d_e;
     PinBuf<double> h_eig, h_small, h_out;
     PinBuf<int32_t> h_int;
 
@@ -150,7 +150,7 @@ struct crab_engine : TreeProgram {
         (void)hipSetDevice(device);
         d_ops.release(); d_codes.release(); d_weights.release(); d_eig.release(); d_teff.release(); d_P.release();
         d_pi.release(); d_props.release(); d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_pidx.release(); d_stack_e.release(); d_e.release();
+        d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_stack_e.release(); d_e.release();
         h_eig.release(); h_small.release(); h_out.release(); h_int.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
@@ -337,14 +337,48 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             p.any_term = true;
         }
     }
-    // prefetch chain: each GEMM op names the node of the next one
-    int next_gemm = -1;
+    // host program: a GEMM op's arg is the index of the next GEMM op (-1 none)
+    int next_gemm_op = -1;
     for (int i = (int)e->ops.size() - 1; i >= 0; --i)
         if (e->ops[i].kind == OP_GEMM) {
-            e->ops[i].arg = next_gemm;
-            next_gemm = e->ops[i].node;
+            e->ops[i].arg = next_gemm_op;
+            next_gemm_op = i;
         }
-    e->first_gemm_node = next_gemm;
+    e->first_gemm_op = next_gemm_op;
+    e->first_leaf_row = -1;
+    for (const TreeOp &op : e->ops)
+        if (op.kind == OP_LEAF) {
+            e->first_leaf_row = op.arg;
+            break;
+        }
+}
+
+// Resolves the topology-only program into K packed device programs: matrix indices instead of node ids, and on
+// each leaf edge the alignment row of the leaf edge after it (whose codes the kernel requests one edge ahead).
+void resolve_programs(const TreeProgram *e, int K, const std::vector<int32_t> &pidx, std::vector<DevOp> &out)
+{
+    const size_t n_ops = e->ops.size(), stride = (size_t)dev_ops_padded((int64_t)n_ops);
+    DevOp filler{};
+    filler.w0 = OP_CONST;
+    out.assign((size_t)K * stride, filler);
+    std::vector<int32_t> next_leaf_row(n_ops, -1);
+    int32_t row = -1;
+    for (int i = (int)n_ops - 1; i >= 0; --i)
+        if (e->ops[i].kind == OP_LEAF) {
+            next_leaf_row[i] = row;
+            row = e->ops[i].arg;
+        }
+    for (int k = 0; k < K; ++k) {
+        const int32_t *pk = pidx.data() + (size_t)k * e->n_nodes;
+        for (size_t i = 0; i < n_ops; ++i) {
+            const TreeOp &op = e->ops[i];
+            DevOp d{};
+            d.w0 = op.kind | (op.flags << 2) | (op.slot << 8);
+            d.mat = op.kind == OP_CONST ? 0 : pk[op.node];
+            d.arg = op.kind == OP_GEMM ? (op.arg >= 0 ? pk[e->ops[op.arg].node] : -1) : op.kind == OP_LEAF ? next_leaf_row[i] : op.arg;
+            out[(size_t)k * stride + i] = d;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -496,11 +530,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_eigen_ms = now_ms() - t0;
 
     // ---- uploads ----
-    if (!e->ops_uploaded) {
-        e->d_ops.ensure(e->ops.size());
-        HIP_CHECK(hipMemcpyAsync(e->d_ops.p, e->ops.data(), e->ops.size() * sizeof(TreeOp), hipMemcpyHostToDevice, e->stream));
-        HIP_CHECK(hipStreamSynchronize(e->stream));  // e->ops is pageable
-        e->ops_uploaded = true;
+    {
+        std::vector<DevOp> progs;
+        resolve_programs(e, pl.K, pl.pidx, progs);
+        if (progs.size() != e->dev_ops.size() || std::memcmp(progs.data(), e->dev_ops.data(), progs.size() * sizeof(DevOp)) != 0) {
+            e->d_ops.ensure(progs.size());
+            HIP_CHECK(hipMemcpyAsync(e->d_ops.p, progs.data(), progs.size() * sizeof(DevOp), hipMemcpyHostToDevice, e->stream));
+            HIP_CHECK(hipStreamSynchronize(e->stream));  // progs is pageable
+            e->dev_ops.swap(progs);
+        }
     }
     const size_t n_small = (size_t)pl.M + NS + pl.K;
     e->h_small.ensure(n_small);
@@ -508,17 +546,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     std::memcpy(hs, pl.t_eff.data(), pl.M * sizeof(double));
     for (int i = 0; i < NS; ++i) hs[pl.M + i] = i < n ? pi[i] : 0.0;
     for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
-    const size_t n_int = (size_t)pl.M + pl.pidx.size();
+    const size_t n_int = (size_t)pl.M;
     e->h_int.ensure(n_int);
     std::memcpy(e->h_int.p, pl.eig_id.data(), pl.M * sizeof(int32_t));
-    std::memcpy(e->h_int.p + pl.M, pl.pidx.data(), pl.pidx.size() * sizeof(int32_t));
 
     e->d_eig.ensure((size_t)pl.n_eig * EIG_STRIDE);
     e->d_teff.ensure(pl.M);
     e->d_pi.ensure(NS);
     e->d_props.ensure(pl.K);
     e->d_eig_id.ensure(pl.M);
-    e->d_pidx.ensure(pl.pidx.size());
     e->d_P.ensure((size_t)pl.M * P_ELEMS);
     const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
     const int grid = prune_grid_size(n_tiles * pl.K);
@@ -536,7 +572,6 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     HIP_CHECK(hipMemcpyAsync(e->d_pi.p, hs + pl.M, NS * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_props.p, hs + pl.M + NS, pl.K * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_eig_id.p, e->h_int.p, pl.M * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipMemcpyAsync(e->d_pidx.p, e->h_int.p + pl.M, pl.pidx.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
@@ -545,9 +580,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
     pa.n_ops = (int32_t)e->ops.size();
+    pa.n_ops_pad = (int32_t)dev_ops_padded((int64_t)e->ops.size());
     pa.P = e->d_P.p;
-    pa.pidx = e->d_pidx.p;
-    pa.n_nodes = e->n_nodes;
     pa.K = pl.K;
     pa.codes = e->d_codes.p;
     pa.n_pat_pad = e->n_pat_pad;
@@ -558,7 +592,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.max_depth = std::max(1, e->max_depth);
     pa.out_f = e->d_f.p;
     pa.out_e = e->d_e.p;
-    pa.first_gemm_node = e->first_gemm_node;
+    pa.first_gemm_op = e->first_gemm_op;
+    pa.first_leaf_row = e->first_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
@@ -698,7 +733,7 @@ int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const in
     if (!e) return CRAB_ERR_ARG;
     return guarded(e, [&] {
         e->have_tree = false;
-        e->ops_uploaded = false;
+        e->dev_ops.clear();
         build_tree(e, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
         e->have_tree = true;
     });

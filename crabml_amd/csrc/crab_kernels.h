@@ -16,9 +16,11 @@ namespace crab {
 //     value in all four 4-lane blocks), so a tile is 16 doubles ordered (k*4 + i').  Tiles s and s+1 are
 //     interleaved so that one 16-byte LDS read feeds two MFMAs:
 //         element (i, j) lives at  (((i>>2)*8 + (j>>3))*16 + (j&3)*4 + (i&3))*2 + ((j>>2)&1)
-//  gather image (doubles [4096, 8192)): column j of P with the 16 states one lane owns contiguous:
-//         element (i, j) lives at  4096 + (j*4 + (i&3))*16 + (i>>2)
-//     so a leaf edge is eight 16-byte loads per lane.
+//  gather image (doubles [4096, 8192)): column j of P (512 contiguous bytes) cut into eight 64-byte pieces; piece q
+//     holds, for each of the four lanes g = i&3 that share a pattern, the two states of register pair q:
+//         element (i, j) lives at  4096 + j*64 + (i>>3)*8 + (i&3)*2 + ((i>>2)&1)
+//     so a leaf edge is eight 16-byte loads per lane and each load instruction touches one half cache line per
+//     pattern (16 lines per wave instruction, not 64).
 //
 // Column n_states (61) holds the row sums sum_j P[i][j] (used for missing data); rows and columns
 // >= n_states are otherwise zero.
@@ -29,7 +31,7 @@ __host__ __device__ inline int p_operand_index(int i, int j)
 {
     return ((((i >> 2) * 8 + (j >> 3)) * 16) + (j & 3) * 4 + (i & 3)) * 2 + ((j >> 2) & 1);
 }
-__host__ __device__ inline int p_gather_index(int i, int j) { return P_IMAGE + (j * 4 + (i & 3)) * 16 + (i >> 2); }
+__host__ __device__ inline int p_gather_index(int i, int j) { return P_IMAGE + j * 64 + (i >> 3) * 8 + (i & 3) * 2 + ((i >> 2) & 1); }
 
 // Conditional likelihoods never touch HBM.  Inside the pruning kernel a wave holds a
 // [64 states x 16 patterns] tile per pattern group: lane l owns pattern (l&15) and the 16 states
@@ -46,14 +48,24 @@ enum : int32_t {
     F_FIN = 8,        // after this op the node is complete: normalise, becomes the operand of the next GEMM
     F_RESCALE = 16    // normalise the running product now (long runs of children)
 };
-struct alignas(16) TreeOp {
+// The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
+// device form (DevOp, matrix indices) before upload, so the kernel never chases the (class, node) -> matrix table.
+struct TreeOp {
     int32_t kind;    // OP_*
-    int32_t node;    // child node whose branch this op crosses (index into the class's P table)
+    int32_t node;    // child node whose branch this op crosses
     int32_t flags;   // F_*
-    int32_t arg;     // LEAF: alignment row; GEMM: node of the next GEMM op (-1 none) for prefetch; CONST: 1 -> ones, 0 -> zeros
+    int32_t arg;     // LEAF: alignment row; GEMM: index of the next GEMM op (-1 none); CONST: 1 -> ones, 0 -> zeros
     int32_t slot;    // stack slot for F_PUSH / F_POP_MUL
-    int32_t pad[3];
 };
+struct alignas(16) DevOp {
+    int32_t w0;      // kind | flags << 2 | slot << 8
+    int32_t mat;     // matrix index of this edge in PruneArgs::P
+    int32_t arg;     // LEAF: alignment row of the NEXT leaf edge (-1 none); GEMM: matrix of the next GEMM op (-1 none);
+                     // CONST: 1 -> ones, 0 -> zeros
+    int32_t pad;
+};
+// Device programs are padded to a multiple of 64 ops plus one extra batch (the kernel reads one batch ahead).
+inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 + 64; }
 
 // ---- kernel 1: batched P(t) = U diag(exp(lam t)) U^-1  (replaces matrix.rs:88-112) -----------
 // For m in [0, M): eigensystem eig + eig_id[m]*EIG_STRIDE, time t_eff[m]; writes P + m*P_ELEMS in
@@ -64,11 +76,10 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // ---- kernel 2: Felsenstein pruning, whole tree per (pattern tile, class)  ---------------------
 // (replaces likelihood.rs:120-132,176-246 and branch_site_likelihood.rs:222-299)
 struct PruneArgs {
-    const TreeOp *ops;
+    const DevOp *ops;         // [K][n_ops_pad] device programs, one per class
     int32_t n_ops;
+    int32_t n_ops_pad;        // dev_ops_padded(n_ops)
     const double *P;          // all matrices of this evaluation
-    const int32_t *pidx;      // [K][n_nodes] -> matrix index in P for (class, node)
-    int32_t n_nodes;
     int32_t K;
     const uint8_t *codes;     // [n_rows][n_pat_pad], values 0..n_states (n_states = missing)
     int64_t n_pat_pad;        // multiple of the tile width
@@ -79,8 +90,8 @@ struct PruneArgs {
     int32_t max_depth;
     double *out_f;            // [K][n_pat_pad]  scaled site likelihood per class
     int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
-    int32_t first_gemm_node;  // node of the first GEMM op (-1 if none)
-    int32_t debug;            // timing ablations (CRAB_DEBUG_SKIP); 0 in production
+    int32_t first_gemm_op;    // index of the first GEMM op (-1 if none)
+    int32_t first_leaf_row;   // alignment row of the first leaf edge in program order (-1 if none)
 };
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();

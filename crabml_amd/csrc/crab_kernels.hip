@@ -15,7 +15,11 @@
 #include "crab_kernels.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <type_traits>
+#include <utility>
 
 namespace crab {
 
@@ -23,6 +27,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
 
 // =============================================================================================
 // kernel 1: batched transition matrices
@@ -92,27 +97,185 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // =============================================================================================
 // kernel 2: pruning
 // =============================================================================================
-// Normalise a [16 states-per-lane x 1 pattern] column group so that its maximum over the 64 states
-// lies in [1, 2): multiply by an exact power of two and book the exponent.  The 64 states of one
-// pattern sit in 16 registers of the 4 lanes {c, c+16, c+32, c+48}.
-__device__ __forceinline__ void normalise(double (&v)[16], int &e)
+// Register plan.  The conditional-likelihood tiles are the only large state of the walk, they live for the whole
+// program, and every op updates them in place.  Left to the register allocator they are re-homed at every merge
+// point of the op-kind branches (hundreds of v_mov_b64 and scratch spills per op).  So the compiler is confined to
+// v[0, R_CC) (amdgpu_num_vgpr) and the tiles and the A-operand ring sit in fixed registers above it, touched only by
+// the asm statements below, which name them through "n" (immediate) operands:
+//     v[R_AV, R_AV+32)        ring of eight 16-byte A-operand reads
+//     v[R_T0, R_T0 + 32 NT)   tile 0: element (nt, idx) in v[R_T0 + 2 (16 nt + idx) : +1]
+//     v[R_T1, R_T1 + 32 NT)   tile 1
+// Element idx of pattern group nt holds state 4 idx + (lane >> 4) of pattern lane & 15 -- the C/D and the B lane map
+// of v_mfma_f64_4x4x4_4b_f64.  Since these registers are invisible to the compiler, every asm that loads into them
+// is followed by an explicit s_waitcnt before the first use.
+constexpr int R_CC = 96;    // registers the compiler may allocate
+constexpr int R_AV = 96;
+constexpr int R_T0 = 128;
+template <int NT>
+constexpr int tile_reg(int t) { return R_T0 + t * 32 * NT; }
+template <int NT>
+constexpr int reg_top() { return R_T0 + 2 * 32 * NT; }
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ---- one-instruction building blocks (register numbers are template arguments) ----
+template <int D, int A, int B, bool FIRST>
+__device__ __forceinline__ void r_mfma()
 {
-    double m = v[0];
+    if constexpr (FIRST)
+        asm volatile("v_mfma_f64_4x4x4_4b_f64 v[%0:%1], v[%2:%3], v[%4:%5], 0" ::"n"(D), "n"(D + 1), "n"(A), "n"(A + 1), "n"(B), "n"(B + 1));
+    else
+        asm volatile("v_mfma_f64_4x4x4_4b_f64 v[%0:%1], v[%2:%3], v[%4:%5], v[%0:%1]" ::"n"(D), "n"(D + 1), "n"(A), "n"(A + 1), "n"(B), "n"(B + 1));
+}
+template <int D, int OFF>
+__device__ __forceinline__ void r_lds_read128(unsigned addr)
+{
+    asm volatile("ds_read_b128 v[%0:%1], %2 offset:%3" ::"n"(D), "n"(D + 3), "v"(addr), "n"(OFF) : "memory");
+}
+template <int X, int Y>
+__device__ __forceinline__ void r_mul()
+{
+    asm volatile("v_mul_f64 v[%0:%1], v[%0:%1], v[%2:%3]" ::"n"(X), "n"(X + 1), "n"(Y), "n"(Y + 1));
+}
+template <int X>
+__device__ __forceinline__ void r_scale(double sc)
+{
+    asm volatile("v_mul_f64 v[%0:%1], v[%0:%1], %2" ::"n"(X), "n"(X + 1), "v"(sc));
+}
+template <int X>
+__device__ __forceinline__ void r_set(double v)
+{
+    asm volatile("v_mov_b64 v[%0:%1], %2" ::"n"(X), "n"(X + 1), "v"(v));
+}
+template <int X>
+__device__ __forceinline__ void r_fma_into(double &f, double m)
+{
+    asm volatile("v_fma_f64 %0, %1, v[%2:%3], %0" : "+v"(f) : "v"(m), "n"(X), "n"(X + 1));
+}
+template <int D, int OFF>
+__device__ __forceinline__ void r_gload128(const void *sbase, unsigned voff)
+{
+    asm volatile("global_load_dwordx4 v[%0:%1], %2, %3 offset:%4" ::"n"(D), "n"(D + 3), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int D, int OFF>
+__device__ __forceinline__ void r_gload64(const void *sbase, unsigned voff)
+{
+    asm volatile("global_load_dwordx2 v[%0:%1], %2, %3 offset:%4" ::"n"(D), "n"(D + 1), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int S, int OFF>
+__device__ __forceinline__ void r_gstore64(void *sbase, unsigned voff)
+{
+    asm volatile("global_store_dwordx2 %2, v[%0:%1], %3 offset:%4" ::"n"(S), "n"(S + 1), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- tile-wide operations ----
+template <int X, int Y, int... I>
+__device__ __forceinline__ void t_mul_seq(std::integer_sequence<int, I...>)
+{
+    (r_mul<X + 2 * I, Y + 2 * I>(), ...);
+}
+// X *= Y, element-wise, NT groups
+template <int NT, int X, int Y>
+__device__ __forceinline__ void t_mul()
+{
+    t_mul_seq<X, Y>(std::make_integer_sequence<int, 16 * NT>{});
+}
+template <int X, int... I>
+__device__ __forceinline__ void t_scale_seq(double sc, std::integer_sequence<int, I...>)
+{
+    (r_scale<X + 2 * I>(sc), ...);
+}
+template <int X, int... I>
+__device__ __forceinline__ void t_set_seq(const double (&v)[16], std::integer_sequence<int, I...>)
+{
+    (r_set<X + 2 * I>(v[I]), ...);
+}
+template <int X, int... I>
+__device__ __forceinline__ void t_dot_seq(double &f, const double (&m)[16], std::integer_sequence<int, I...>)
+{
+    (r_fma_into<X + 2 * I>(f, m[I]), ...);
+}
+// 16-byte column pieces of one pattern group: eight loads of 16 bytes, 64 bytes apart
+template <int D, int... Q>
+__device__ __forceinline__ void t_gather_seq(const void *sbase, unsigned voff, std::integer_sequence<int, Q...>)
+{
+    (r_gload128<D + 4 * Q, 64 * Q>(sbase, voff), ...);
+}
+// stack slot <-> tile: element e of the tile sits 512 bytes after element e-1 (64 lanes x 8 bytes per element);
+// the instruction offset reaches 4 KiB, so every eighth element starts a new lane offset
+template <int D, int E0, int... I>
+__device__ __forceinline__ void t_load8(const void *sbase, unsigned voff, std::integer_sequence<int, I...>)
+{
+    (r_gload64<D + 2 * (E0 + I), 512 * I>(sbase, voff), ...);
+}
+template <int S, int E0, int... I>
+__device__ __forceinline__ void t_store8(void *sbase, unsigned voff, std::integer_sequence<int, I...>)
+{
+    (r_gstore64<S + 2 * (E0 + I), 512 * I>(sbase, voff), ...);
+}
+template <int NT, int D>
+__device__ __forceinline__ void t_load(const void *sbase, unsigned voff)
+{
+    using S8 = std::make_integer_sequence<int, 8>;
+    t_load8<D, 0>(sbase, voff, S8{});
+    t_load8<D, 8>(sbase, voff + 4096, S8{});
+    if constexpr (NT == 2) {
+        t_load8<D, 16>(sbase, voff + 8192, S8{});
+        t_load8<D, 24>(sbase, voff + 12288, S8{});
+    }
+}
+template <int NT, int S>
+__device__ __forceinline__ void t_store(void *sbase, unsigned voff)
+{
+    using S8 = std::make_integer_sequence<int, 8>;
+    t_store8<S, 0>(sbase, voff, S8{});
+    t_store8<S, 8>(sbase, voff + 4096, S8{});
+    if constexpr (NT == 2) {
+        t_store8<S, 16>(sbase, voff + 8192, S8{});
+        t_store8<S, 24>(sbase, voff + 12288, S8{});
+    }
+}
+
+// Largest high word over the 16 elements of group nt (conditional likelihoods are non-negative, so the largest
+// value is the one with the largest high word), then over the four lanes c, c+16, c+32, c+48 that share a pattern.
+template <int X>
+__device__ __forceinline__ int t_max_hi()
+{
+    int hi;
+    asm volatile("v_max3_i32 %0, v[%1], v[%2], v[%3]" : "=v"(hi) : "n"(X + 1), "n"(X + 3), "n"(X + 5));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 7), "n"(X + 9));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 11), "n"(X + 13));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 15), "n"(X + 17));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 19), "n"(X + 21));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 23), "n"(X + 25));
+    asm volatile("v_max3_i32 %0, %0, v[%1], v[%2]" : "+v"(hi) : "n"(X + 27), "n"(X + 29));
+    asm volatile("v_max_i32 %0, %0, v[%1]" : "+v"(hi) : "n"(X + 31));
+    auto r16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);  // row swaps: no LDS traffic
+    hi = (int)r16[0] > (int)r16[1] ? (int)r16[0] : (int)r16[1];
+    auto r32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return (int)r32[0] > (int)r32[1] ? (int)r32[0] : (int)r32[1];
+}
+// Normalise tile X so that each pattern's maximum over the 64 states lies in [1, 2): multiply by an exact power of
+// two and book the exponent.
+template <int NT, int X>
+__device__ __forceinline__ void t_normalise(int (&e)[NT])
+{
+    static_assert(NT <= 2, "");
+    int hi[NT];
+    hi[0] = t_max_hi<X>();
+    if constexpr (NT == 2) hi[1] = t_max_hi<X + 32>();
 #pragma unroll
-    for (int i = 1; i < 16; ++i) m = v[i] > m ? v[i] : m;
-    double o = __shfl_xor(m, 16);
-    m = o > m ? o : m;
-    o = __shfl_xor(m, 32);
-    m = o > m ? o : m;
-    if (m > 0.0 && m < __builtin_inf()) {
-        int ex = (int)((__double_as_longlong(m) >> 52) & 0x7ff) - 1023;
-        ex = ex < -1022 ? -1022 : (ex > 1022 ? 1022 : ex);
-        if (ex != 0) {
-            const double sc = __longlong_as_double((long long)(1023 - ex) << 52);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] *= sc;
-            e += ex;
-        }
+    for (int nt = 0; nt < NT; ++nt) {
+        int ex = ((hi[nt] >> 20) & 0x7ff) - 1023;  // biased exponent of the maximum
+        const bool ok = hi[nt] >= 0x00100000 && hi[nt] < 0x7ff00000;  // positive, normal, finite
+        ex = ok ? (ex > 1022 ? 1022 : ex) : 0;
+        const double sc = __hiloint2double((1023 - ex) << 20, 0);
+        if (nt == 0)
+            t_scale_seq<X>(sc, std::make_integer_sequence<int, 16>{});
+        else
+            t_scale_seq<X + 32>(sc, std::make_integer_sequence<int, 16>{});
+        e[nt] += ex;
     }
 }
 
@@ -126,181 +289,259 @@ __device__ __forceinline__ void dma_matrix(const double *Pm, char *lds_buf, int 
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc + i * 1024), LDS_PTR(ldst + i * 1024), 16, 0, 0);
 }
 
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-template <int NT>
-__global__ __launch_bounds__(256, 4) void prune_kernel(PruneArgs a, long long n_tiles)
+// Y = P * X for NT pattern groups: 256*NT MFMAs fed by 128 ds_read_b128, P's operand image in LDS at lds_addr.
+// Group GI = (sp, ic) covers k-tiles 2sp, 2sp+1 and state groups 4ic..4ic+3.  Read q of group GI+1 is issued just
+// before the MFMAs that consume read q of group GI, so every read has 8*NT MFMAs (>= 128 cycles) to land; between
+// the two MFMAs into one accumulator lie 4*NT independent ones.  Measured alone: 74-76 TFLOP/s (scripts/micro).
+template <int NT, int X, int Y, int GI, int Q>
+__device__ __forceinline__ void gemm_first_half(unsigned lds_addr)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // one 32 KiB operand image
+    constexpr int sp = GI >> 2, ic = GI & 3, b = GI & 1;
+    if constexpr (GI + 1 < 32) {
+        constexpr int sp1 = (GI + 1) >> 2, ic1 = (GI + 1) & 3;
+        r_lds_read128<R_AV + ((b ^ 1) * 4 + Q) * 4, ((ic1 * 4 + Q) * 8 + sp1) * 256>(lds_addr);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 - Q) : "memory");
+    }
+    constexpr int A = R_AV + (b * 4 + Q) * 4;
+    r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp), sp == 0>();
+    if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp), sp == 0>();
+    if constexpr (Q + 1 < 4) gemm_first_half<NT, X, Y, GI, Q + 1>(lds_addr);
+}
+template <int NT, int X, int Y, int GI, int Q>
+__device__ __forceinline__ void gemm_second_half()
+{
+    constexpr int sp = GI >> 2, ic = GI & 3, b = GI & 1;
+    constexpr int A = R_AV + (b * 4 + Q) * 4 + 2;
+    r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp + 1), false>();
+    if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp + 1), false>();
+    if constexpr (Q + 1 < 4) gemm_second_half<NT, X, Y, GI, Q + 1>();
+}
+template <int NT, int X, int Y, int GI>
+__device__ __forceinline__ void gemm_group(unsigned lds_addr)
+{
+    gemm_first_half<NT, X, Y, GI, 0>(lds_addr);
+    gemm_second_half<NT, X, Y, GI, 0>();
+    if constexpr (GI + 1 < 32) gemm_group<NT, X, Y, GI + 1>(lds_addr);
+}
+template <int NT, int X, int Y>
+__device__ __forceinline__ void gemm_tile(unsigned lds_addr)
+{
+    r_lds_read128<R_AV + 0, 0 * 2048>(lds_addr);
+    r_lds_read128<R_AV + 4, 1 * 2048>(lds_addr);
+    r_lds_read128<R_AV + 8, 2 * 2048>(lds_addr);
+    r_lds_read128<R_AV + 12, 3 * 2048>(lds_addr);
+    gemm_group<NT, X, Y, 0>(lds_addr);
+    // the hardware does not interlock MFMA results against the VALU / memory instructions that read them next
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+// State of one wave's walk that is not a register tile.
+template <int NT>
+struct Walk {
+    const PruneArgs &a;
+    const DevOp *ops;          // this class's program
+    DevOp batch;               // 64 ops, one per lane, decoded with v_readlane
+    int ip;                    // next op
+    int buf;                   // LDS buffer holding the operand image of the next product
+    unsigned code_off[NT];     // byte offset of the next leaf edge's column inside a gather image, per pattern group
+    const uint8_t *codes;      // this lane's column of the code table
+    const char *gather0;       // gather image of matrix 0
+    char *stack;               // this wave's stack area (uniform) ...
+    int32_t *stack_e;          // ... and this lane's element of its exponent area
+    unsigned lane_off8;        // lane * 8
+    unsigned lds_a;            // LDS byte address of this lane's A operand inside a tile pair
+    char *smem;
+    int wave, lane;
+};
+
+// Runs the program on the current tile X (exponents eX) until a product Y = P X has been executed (returns false:
+// Y is the current tile now and X is free) or the program ends (returns true: X is the root's tile).
+// The other tile Y is dead on entry and serves as landing zone for columns and saved products.  Every update of
+// the current tile is in place and the two tiles swap roles only at a product, so no tile is ever copied.
+template <int NT, int X, int Y>
+__device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
+{
+    constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
+    const PruneArgs &a = w.a;
+
+    while (w.ip < a.n_ops) {
+        const int il = w.ip & 63;
+        if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
+        const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
+        const int kind = w0 & 3, flags = (w0 >> 2) & 63, slot = w0 >> 8;
+        const int mat = __builtin_amdgcn_readlane(w.batch.mat, il);
+        const int arg = __builtin_amdgcn_readlane(w.batch.arg, il);
+        ++w.ip;
+
+        if (kind == OP_GEMM) {
+            // this edge's operand image was requested one product ago; wait for this wave's share of it, and
+            // (barrier) for everybody's: all waves have then also left the product that read the other buffer
+            r_wait_vm0();
+            __syncthreads();
+            if (arg >= 0) dma_matrix(a.P + (size_t)arg * P_ELEMS, w.smem + (w.buf ^ 1) * 32768, w.wave, w.lane);
+            gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768);
+            w.buf ^= 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) eY[nt] = eX[nt];
+            if (flags & F_POP_MUL) {
+                // X has been consumed: its registers receive the saved sibling product
+                const int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+                int es[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) es[nt] = se[nt * 64];
+                t_load<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+                r_wait_vm0();
+                t_mul<NT, Y, X>();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) eY[nt] += es[nt];
+            }
+            if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, Y>(eY);
+            if (flags & F_PUSH) {
+                int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eY[nt];
+                t_store<NT, Y>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+            }
+            return false;
+        }
+
+        if (kind == OP_LEAF) {
+            // P[i][code] for the 16 states of this lane, from the edge's gather image (L2-resident, shared by every
+            // workgroup walking this class); the codes were requested one leaf edge ago
+            const char *img = w.gather0 + (size_t)mat * (P_ELEMS * 8);
+            using S8 = std::make_integer_sequence<int, 8>;
+            if (flags & F_MUL_PROD) {
+                t_gather_seq<Y>(img, w.code_off[0], S8{});
+                if constexpr (NT == 2) t_gather_seq<Y + 32>(img, w.code_off[1], S8{});
+            } else {
+                t_gather_seq<X>(img, w.code_off[0], S8{});
+                if constexpr (NT == 2) t_gather_seq<X + 32>(img, w.code_off[1], S8{});
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
+            }
+            if (arg >= 0) {
+                const uint8_t *r = w.codes + (size_t)arg * a.n_pat_pad;
+                unsigned code[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
+            }
+            if (arg >= 0)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");  // the columns have landed; the next codes may still fly
+            else
+                r_wait_vm0();
+            if (flags & F_MUL_PROD) t_mul<NT, X, Y>();
+        } else {  // OP_CONST: childless non-leaf node
+            double v[16];
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) v[idx] = (arg && 4 * idx + (w.lane >> 4) < a.n_states) ? 1.0 : 0.0;
+            t_set_seq<X>(v, std::make_integer_sequence<int, 16>{});
+            if constexpr (NT == 2) t_set_seq<X + 32>(v, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
+        }
+        if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, X>(eX);
+        if (flags & F_PUSH) {
+            int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eX[nt];
+            t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+        }
+    }
+    return true;
+}
+
+// root: f = sum_i pi_i L_root[i]   (likelihood.rs:236-243)
+template <int NT, int X>
+__device__ __forceinline__ void root_sum(const PruneArgs &a, const int (&eX)[NT], size_t out0, int g)
+{
+    double pi[16];
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) pi[idx] = a.pi_pad[4 * idx + g];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        double f = 0.0;
+        if (nt == 0)
+            t_dot_seq<X>(f, pi, std::make_integer_sequence<int, 16>{});
+        else
+            t_dot_seq<X + 32>(f, pi, std::make_integer_sequence<int, 16>{});
+        f += __shfl_xor(f, 16);
+        f += __shfl_xor(f, 32);
+        if (g == 0) {
+            a.out_f[out0 + nt * 16] = f;
+            a.out_e[out0 + nt * 16] = eX[nt];
+        }
+    }
+}
+
+// One workgroup = 4 waves = 64*NT patterns of one site class; each wave walks the whole tree program for its 16*NT
+// patterns with two register tiles (see walk()).  The program is per class (matrix indices resolved on the host),
+// so the only dependent global reads on the walk are the leaf-edge column gathers.
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void prune_kernel(PruneArgs a, long long n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // two 32 KiB operand images
+    constexpr int X0 = tile_reg<NT>(0), X1 = tile_reg<NT>(1);
+    // the highest fixed register, named once so that the kernel descriptor allocates the whole plan
+    if constexpr (NT == 1)
+        asm volatile("" ::: "v191");
+    else
+        asm volatile("" ::: "v255");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const long long n_work = n_tiles * a.K;
+    constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
 
-    const size_t slot_doubles = (size_t)NT * 16 * 64;
-    double *my_stack = a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_doubles + lane;
-    int32_t *my_stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;
-    // this lane's A operand inside a tile pair: element (k = g, i' = lane&3), two consecutive doubles
-    const v2d *A2 = (const v2d *)smem + (g * 4 + (lane & 3));
-
-    for (long long w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const int cls = (int)(w / n_tiles);
-        const long long tile = w - (long long)cls * n_tiles;
+    for (long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const int cls = (int)(wi / n_tiles);
+        const long long tile = wi - (long long)cls * n_tiles;
         const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
-        const int32_t *pidx = a.pidx + (size_t)cls * a.n_nodes;
 
-        double cur[NT][16], prod[NT][16];
-        int ecur[NT], eprod[NT];
+        Walk<NT> w{a};
+        w.ops = a.ops + (size_t)cls * a.n_ops_pad;
+        w.ip = 0;
+        w.buf = 0;
+        w.codes = a.codes + pat0;
+        w.gather0 = (const char *)(a.P + P_IMAGE);
+        w.stack = (char *)a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_bytes;
+        w.stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;
+        w.lane_off8 = lane * 8;
+        w.lds_a = (unsigned)(size_t)LDS_PTR(smem) + (g * 4 + (lane & 3)) * 16;
+        w.smem = smem;
+        w.wave = wave;
+        w.lane = lane;
+
+        int e0[NT], e1[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            ecur[nt] = 0;
-            eprod[nt] = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cur[nt][i] = prod[nt][i] = 0.0;
+            e0[nt] = e1[nt] = 0;
+            w.code_off[nt] = (unsigned)a.n_states * 512u + (unsigned)g * 16u;
         }
 
         __syncthreads();  // every wave is done reading LDS for the previous work item
-        if (a.first_gemm_node >= 0 && !(a.debug & 8)) dma_matrix(a.P + (size_t)pidx[a.first_gemm_node] * P_ELEMS, smem, wave, lane);
-
-        for (int ip = 0; ip < a.n_ops; ++ip) {
-            const TreeOp op = a.ops[ip];
-            double t[NT][16];
-            int et[NT];
-
-            if (op.kind == OP_GEMM) {
-                // the operand image of this edge was requested right after the previous product
-                if (!(a.debug & 8)) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                }
+        if (a.first_gemm_op >= 0) dma_matrix(a.P + (size_t)w.ops[a.first_gemm_op].mat * P_ELEMS, smem, wave, lane);
+        // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
+        w.batch = w.ops[lane];
+        if (a.first_leaf_row >= 0) {
+            const uint8_t *r = w.codes + (size_t)a.first_leaf_row * a.n_pat_pad;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) t[nt][i] = 0.0;
-                if (!(a.debug & 4)) {
-#pragma unroll
-                    for (int sp = 0; sp < 8; ++sp) {
-#pragma unroll
-                        for (int ic = 0; ic < 4; ++ic) {
-                            v2d av[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) av[q] = A2[((ic * 4 + q) * 8 + sp) * 16];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    t[nt][ic * 4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q][0], cur[nt][2 * sp], t[nt][ic * 4 + q], 0, 0, 0);
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    t[nt][ic * 4 + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[q][1], cur[nt][2 * sp + 1], t[nt][ic * 4 + q], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) et[nt] = ecur[nt];
-                if (!(a.debug & 8)) {
-                    __syncthreads();  // all four waves have read the image: the buffer is free for the next edge
-                    if (op.arg >= 0) dma_matrix(a.P + (size_t)pidx[op.arg] * P_ELEMS, smem, wave, lane);
-                }
-            } else if (op.kind == OP_LEAF) {
-                // P[i][code] for the 16 states i = 4*idx + g of this lane: 128 contiguous bytes of the gather
-                // image in global memory (L2-resident, shared by every workgroup walking this class)
-                const v2d *G2 = (const v2d *)(a.P + (size_t)pidx[op.node] * P_ELEMS + P_IMAGE) + g * 8;
-                const uint8_t *row = a.codes + (size_t)op.arg * a.n_pat_pad + pat0;
-                if (a.debug & 1) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        et[nt] = 0;
-#pragma unroll
-                        for (int idx = 0; idx < 16; ++idx) t[nt][idx] = 0.5;
-                    }
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int code = row[nt * 16];
-                        const v2d *col = G2 + code * 32;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const v2d v = col[q];
-                            t[nt][2 * q] = v[0];
-                            t[nt][2 * q + 1] = v[1];
-                        }
-                        et[nt] = 0;
-                    }
-                }
-            } else {  // OP_CONST: childless non-leaf node
-                const double v = op.arg ? 1.0 : 0.0;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    et[nt] = 0;
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) t[nt][idx] = (4 * idx + g < a.n_states) ? v : 0.0;
-                }
-            }
-
-            if (op.flags & F_MUL_PROD) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    et[nt] += eprod[nt];
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) t[nt][idx] *= prod[nt][idx];
-                }
-            }
-            if ((op.flags & F_POP_MUL) && !(a.debug & 2)) {
-                const double *sp = my_stack + (size_t)op.slot * slot_doubles;
-                const int32_t *se = my_stack_e + (size_t)op.slot * (NT * 64);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    et[nt] += se[nt * 64];
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) t[nt][idx] *= sp[(nt * 16 + idx) * 64];
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                eprod[nt] = et[nt];
-#pragma unroll
-                for (int idx = 0; idx < 16; ++idx) prod[nt][idx] = t[nt][idx];
-            }
-            if (op.flags & (F_FIN | F_RESCALE)) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) normalise(prod[nt], eprod[nt]);
-            }
-            if ((op.flags & F_PUSH) && !(a.debug & 2)) {
-                double *sp = my_stack + (size_t)op.slot * slot_doubles;
-                int32_t *se = my_stack_e + (size_t)op.slot * (NT * 64);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    se[nt * 64] = eprod[nt];
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) sp[(nt * 16 + idx) * 64] = prod[nt][idx];
-                }
-            }
-            if (op.flags & F_FIN) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    ecur[nt] = eprod[nt];
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) cur[nt][idx] = prod[nt][idx];
-                }
-            }
+            for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = (unsigned)r[nt * 16] * 512u + (unsigned)g * 16u;
         }
 
-        // root: f = sum_i pi_i L_root[i]   (likelihood.rs:236-243)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double f = 0.0;
-#pragma unroll
-            for (int idx = 0; idx < 16; ++idx) f += a.pi_pad[4 * idx + g] * cur[nt][idx];
-            f += __shfl_xor(f, 16);
-            f += __shfl_xor(f, 32);
-            if (g == 0) {
-                const size_t o = (size_t)cls * a.n_pat_pad + pat0 + nt * 16;
-                a.out_f[o] = f;
-                a.out_e[o] = ecur[nt];
+        const size_t out0 = (size_t)cls * a.n_pat_pad + pat0;
+        for (;;) {
+            if (walk<NT, X0, X1>(w, e0, e1)) {
+                root_sum<NT, X0>(a, e0, out0, g);
+                break;
+            }
+            if (walk<NT, X1, X0>(w, e1, e0)) {
+                root_sum<NT, X1>(a, e1, out0, g);
+                break;
             }
         }
     }
@@ -310,7 +551,7 @@ static int g_nt = 0;
 static int chosen_nt()
 {
     if (g_nt == 0) {
-        g_nt = 1;
+        g_nt = 2;
         if (const char *s = std::getenv("CRAB_NT")) {
             const int v = std::atoi(s);
             if (v == 1 || v == 2) g_nt = v;
@@ -318,16 +559,17 @@ static int chosen_nt()
     }
     return g_nt;
 }
-constexpr size_t PRUNE_LDS_BYTES = P_IMAGE * sizeof(double);
+static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double); }
 static int g_blocks_per_cu = 0;
 static int blocks_per_cu()
 {
     if (g_blocks_per_cu == 0) {
         int occ = 0;
         const hipError_t err = chosen_nt() == 1
-                                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<1>, 256, PRUNE_LDS_BYTES)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<2>, 256, PRUNE_LDS_BYTES);
-        g_blocks_per_cu = (err == hipSuccess && occ >= 1) ? (occ > 4 ? 4 : occ) : 1;
+                                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<1>, 256, prune_lds_bytes())
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<2>, 256, prune_lds_bytes());
+        const int want = 2;
+        g_blocks_per_cu = (err == hipSuccess && occ >= 1) ? (occ > want ? want : occ) : 1;
         if (const char *s = std::getenv("CRAB_BLOCKS_PER_CU")) {
             const int v = std::atoi(s);
             if (v >= 1 && v <= g_blocks_per_cu) g_blocks_per_cu = v;
@@ -352,18 +594,39 @@ int prune_grid_size(int64_t n_work)
 size_t prune_stack_doubles(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 16 * 64; }
 size_t prune_stack_ints(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 64; }
 
-void launch_prune(const PruneArgs &a_in, int grid, hipStream_t stream)
+void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
 {
-    if (grid <= 0 || a_in.n_ops <= 0) return;
-    PruneArgs a = a_in;
-    if (const char *s = std::getenv("CRAB_DEBUG_SKIP")) a.debug = std::atoi(s);  // timing ablations only: wrong results
+    if (grid <= 0 || a.n_ops <= 0) return;
     const int nt = chosen_nt();
     const long long n_tiles = a.n_pat_pad / (64 * nt);
-    const size_t lds = PRUNE_LDS_BYTES;
+    const size_t lds = prune_lds_bytes();
+#ifdef CRAB_PROF
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) {
+        (void)hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 12 * 4 * 4096);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &d_prof, sizeof(d_prof));
+    }
+    (void)hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 12 * 4 * 4096, stream);
+#endif
     if (nt == 1)
         hipLaunchKernelGGL(prune_kernel<1>, dim3(grid), dim3(256), lds, stream, a, n_tiles);
     else
         hipLaunchKernelGGL(prune_kernel<2>, dim3(grid), dim3(256), lds, stream, a, n_tiles);
+#ifdef CRAB_PROF
+    {
+        (void)hipStreamSynchronize(stream);
+        static const char *names[12] = {"prologue+root", "gemm wait vmcnt+barrier", "gemm issue dma/prefetch", "gemm mfma", "gemm post (barrier/dma/pop)",
+                                        "leaf wait", "leaf multiply", "normalise", "push", "fin copy+misc", "late prefetch+op advance", "op decode"};
+        std::vector<unsigned long long> h((size_t)grid * 4 * 12);
+        (void)hipMemcpy(h.data(), d_prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double tot[12] = {0}, all = 0;
+        for (size_t wv = 0; wv < (size_t)grid * 4; ++wv)
+            for (int i = 0; i < 12; ++i) tot[i] += (double)h[wv * 12 + i];
+        for (int i = 0; i < 12; ++i) all += tot[i];
+        fprintf(stderr, "[crab prof] NT=%d grid=%d: mean cycles per wave %.0f\n", nt, grid, all / (grid * 4.0));
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "[crab prof]   %-28s %10.0f  %5.1f %%\n", names[i], tot[i] / (grid * 4.0), 100.0 * tot[i] / all);
+    }
+#endif
 }
 
 // =============================================================================================

@@ -1,0 +1,63 @@
+// Microbenchmark: the pruning kernel's product core (gemm_tile) in isolation -- A operand image resident in LDS,
+// conditional likelihoods in registers, R chained products per wave, no tree walk.  Gives the ceiling the whole
+// kernel can reach with this core at a given occupancy.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I crabml_amd/csrc scripts/micro/gemm_tile_rate.hip -o /tmp/gtr && /tmp/gtr
+#include "../../crabml_amd/csrc/crab_kernels.hip"
+#include <cstdio>
+using namespace crab;
+
+template <int NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k(double *out, const double *img, int reps)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    for (int i = threadIdx.x; i < 4096; i += 256) ((double *)smem)[i] = img[i];
+    __syncthreads();
+    const unsigned lds_a = (unsigned)(size_t)LDS_PTR(smem) + (g * 4 + (lane & 3)) * 16;
+    double cur[NT][16], acc[NT][16];
+    for (int nt = 0; nt < NT; ++nt)
+        for (int i = 0; i < 16; ++i) cur[nt][i] = 1.0 + 0.001 * (threadIdx.x + i + nt);
+    for (int r = 0; r < reps; ++r) {
+        gemm_tile<NT>(lds_a, cur, acc);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int i = 0; i < 16; ++i) cur[nt][i] = acc[nt][i];
+    }
+    double s = 0;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int i = 0; i < 16; ++i) s += cur[nt][i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NT, int WPS>
+void run(int blocks_per_cu)
+{
+    const int grid = 256 * blocks_per_cu, reps = 400;
+    double *out, *img;
+    (void)hipMalloc(&out, sizeof(double) * grid * 256);
+    (void)hipMalloc(&img, sizeof(double) * 4096);
+    std::vector<double> h(4096, 1.0 / 64);
+    (void)hipMemcpy(img, h.data(), sizeof(double) * 4096, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<NT, WPS>), dim3(grid), dim3(256), 32768, 0, out, img, reps);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<NT, WPS>), dim3(grid), dim3(256), 32768, 0, out, img, reps);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)grid * 4 * reps * NT * 256 * 512.0;
+    printf("gemm_tile NT=%d waves/SIMD=%d: %.3f ms  %.2f TFLOP/s (64-padded)  %.1f cycles/MFMA/SIMD @2.4GHz\n", NT, blocks_per_cu, ms, flop / ms / 1e9,
+           ms * 1e-3 * 2.4e9 / ((double)reps * NT * 256 * blocks_per_cu));
+    (void)hipFree(out);
+    (void)hipFree(img);
+}
+
+int main()
+{
+    run<1, 4>(1); run<1, 4>(2); run<1, 4>(4);
+    run<2, 2>(1); run<2, 2>(2);
+    return 0;
+}

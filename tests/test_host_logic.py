@@ -132,9 +132,9 @@ def test_program_of_random_trees_and_stack_depth(oracle):
         _, site = oracle.compute_log_likelihood(case.Q[0], case.pi, case.tree_structure, case.branch_lengths, None, case.codes,
                                                 case.leaf_node_ids, return_sites=True)
         np.testing.assert_allclose(np.log(f), site, rtol=1e-11)
-        # prefetch chain: every GEMM names the next GEMM's node
-        gemm = ops[ops[:, 0] == 0]
-        assert list(gemm[:-1, 3]) == list(gemm[1:, 1]) and gemm[-1, 3] == -1
+        # prefetch chain: every GEMM names the index of the next GEMM op
+        gemm_idx = np.flatnonzero(ops[:, 0] == 0)
+        assert list(ops[gemm_idx[:-1], 3]) == list(gemm_idx[1:]) and ops[gemm_idx[-1], 3] == -1
 
 
 def test_caterpillar_and_star_trees():
