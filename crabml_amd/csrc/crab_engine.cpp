@@ -110,7 +110,7 @@ struct TreeProgram {
     std::vector<int> parent, child_start, child, leaf_row;
     std::vector<char> in_leaf_set, reachable;
     std::vector<TreeOp> ops;
-    int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1;
+    int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1;
     int64_t n_gemm_edges = 0, n_leaf_edges = 0;
 };
 
@@ -345,12 +345,39 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             next_gemm_op = i;
         }
     e->first_gemm_op = next_gemm_op;
-    e->first_leaf_row = -1;
-    for (const TreeOp &op : e->ops)
+    // ---- pass 4: leaf-edge prefetch schedule.  A wave owns one prefetch tile.  The columns of a leaf edge are
+    // requested at the first product (GEMM) after the previous leaf edge was consumed, so that the gather latency
+    // hides under MFMA work, or at the end of the op just before it when no product lies in between. ----
+    std::vector<int> leaf_ops;
+    for (int i = 0; i < (int)e->ops.size(); ++i) {
+        e->ops[i].pre_node = -1;
+        e->ops[i].pre_row2 = -1;
+        if (e->ops[i].kind == OP_LEAF) leaf_ops.push_back(i);
+    }
+    e->first_leaf_row = leaf_ops.empty() ? -1 : e->ops[leaf_ops[0]].arg;
+    e->second_leaf_row = leaf_ops.size() > 1 ? e->ops[leaf_ops[1]].arg : -1;
+    e->first_leaf_op = (!leaf_ops.empty() && leaf_ops[0] == 0) ? 0 : -1;
+    size_t li = 0;                               // leaf_ops[li] = next leaf edge not yet consumed
+    bool requested = e->first_leaf_op == 0;      // its columns have been requested (the prefetch tile is busy)
+    auto request_at = [&](TreeOp &op, int flag) {
+        op.flags |= flag;
+        op.pre_node = e->ops[leaf_ops[li]].node;
+        op.pre_row2 = li + 1 < leaf_ops.size() ? e->ops[leaf_ops[li + 1]].arg : -1;
+        requested = true;
+    };
+    for (int i = 0; i < (int)e->ops.size(); ++i) {
+        TreeOp &op = e->ops[i];
+        const bool next_is_leaf = i + 1 < (int)e->ops.size() && e->ops[i + 1].kind == OP_LEAF;
         if (op.kind == OP_LEAF) {
-            e->first_leaf_row = op.arg;
-            break;
+            requested = false;  // consumed here
+            ++li;
+            if (next_is_leaf) request_at(op, F_PRE_LATE);
+        } else if (op.kind == OP_GEMM) {
+            if (!requested && li < leaf_ops.size()) request_at(op, F_PRE_EARLY);
+        } else if (!requested && next_is_leaf) {
+            request_at(op, F_PRE_LATE);
         }
+    }
 }
 
 // Resolves the topology-only program into K packed device programs: matrix indices instead of node ids, and on
@@ -373,7 +400,9 @@ void resolve_programs(const TreeProgram *e, int K, const std::vector<int32_t> &p
         for (size_t i = 0; i < n_ops; ++i) {
             const TreeOp &op = e->ops[i];
             DevOp d{};
-            d.w0 = op.kind | (op.flags << 2) | (op.slot << 8);
+            d.w0 = op.kind | (op.flags << 2) | (op.slot << 9);
+            d.pre_mat = op.pre_node >= 0 ? pk[op.pre_node] : -1;
+            d.pre_row2 = op.pre_row2;
             d.mat = op.kind == OP_CONST ? 0 : pk[op.node];
             d.arg = op.kind == OP_GEMM ? (op.arg >= 0 ? pk[e->ops[op.arg].node] : -1) : op.kind == OP_LEAF ? next_leaf_row[i] : op.arg;
             out[(size_t)k * stride + i] = d;
@@ -594,6 +623,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.out_e = e->d_e.p;
     pa.first_gemm_op = e->first_gemm_op;
     pa.first_leaf_row = e->first_leaf_row;
+    pa.first_leaf_op = e->first_leaf_op;
+    pa.second_leaf_row = e->second_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));

@@ -46,7 +46,11 @@ enum : int32_t {
     F_POP_MUL = 2,    // multiply the new term with stack[slot] (the product saved before a sibling subtree)
     F_PUSH = 4,       // after this op, save the running product in stack[slot]
     F_FIN = 8,        // after this op the node is complete: normalise, becomes the operand of the next GEMM
-    F_RESCALE = 16    // normalise the running product now (long runs of children)
+    F_RESCALE = 16,   // normalise the running product now (long runs of children)
+    // leaf-edge prefetch schedule (used by kernels that keep a prefetch tile): the columns of the next leaf edge are
+    // requested while a product runs, or at the end of the op just before that leaf edge
+    F_PRE_EARLY = 32, // GEMM: before the product starts, request the columns of leaf edge pre_node
+    F_PRE_LATE = 64   // any op: at its end, request the columns of leaf edge pre_node (the next op is that leaf edge)
 };
 // The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
 // device form (DevOp, matrix indices) before upload, so the kernel never chases the (class, node) -> matrix table.
@@ -56,13 +60,17 @@ struct TreeOp {
     int32_t flags;   // F_*
     int32_t arg;     // LEAF: alignment row; GEMM: index of the next GEMM op (-1 none); CONST: 1 -> ones, 0 -> zeros
     int32_t slot;    // stack slot for F_PUSH / F_POP_MUL
+    int32_t pre_node;  // F_PRE_*: child node of the leaf edge whose columns are requested
+    int32_t pre_row2;  // F_PRE_*: alignment row of the leaf edge after that one (its codes are requested too), -1 none
 };
 struct alignas(16) DevOp {
-    int32_t w0;      // kind | flags << 2 | slot << 8
-    int32_t mat;     // matrix index of this edge in PruneArgs::P
-    int32_t arg;     // LEAF: alignment row of the NEXT leaf edge (-1 none); GEMM: matrix of the next GEMM op (-1 none);
-                     // CONST: 1 -> ones, 0 -> zeros
-    int32_t pad;
+    int32_t w0;        // kind | flags << 2 | slot << 9
+    int32_t mat;       // matrix index of this edge in PruneArgs::P
+    int32_t arg;       // LEAF: alignment row of the NEXT leaf edge (-1 none); GEMM: matrix of the next GEMM op (-1 none);
+                       // CONST: 1 -> ones, 0 -> zeros
+    int32_t pre_mat;   // F_PRE_*: matrix of the leaf edge whose columns are requested
+    int32_t pre_row2;  // F_PRE_*: alignment row whose codes are requested with them (-1 none)
+    int32_t pad[3];
 };
 // Device programs are padded to a multiple of 64 ops plus one extra batch (the kernel reads one batch ahead).
 inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 + 64; }
@@ -92,6 +100,8 @@ struct PruneArgs {
     int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
     int32_t first_gemm_op;    // index of the first GEMM op (-1 if none)
     int32_t first_leaf_row;   // alignment row of the first leaf edge in program order (-1 if none)
+    int32_t first_leaf_op;    // index of that op if it is op 0 (its columns are requested before the walk starts), else -1
+    int32_t second_leaf_row;  // alignment row of the second leaf edge (-1 if none)
 };
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();

@@ -100,21 +100,37 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // Register plan.  The conditional-likelihood tiles are the only large state of the walk, they live for the whole
 // program, and every op updates them in place.  Left to the register allocator they are re-homed at every merge
 // point of the op-kind branches (hundreds of v_mov_b64 and scratch spills per op).  So the compiler is confined to
-// v[0, R_CC) (amdgpu_num_vgpr) and the tiles and the A-operand ring sit in fixed registers above it, touched only by
+// v[0, CC) (amdgpu_num_vgpr) and the tiles and the A-operand ring sit in fixed registers above it, touched only by
 // the asm statements below, which name them through "n" (immediate) operands:
-//     v[R_AV, R_AV+32)        ring of eight 16-byte A-operand reads
-//     v[R_T0, R_T0 + 32 NT)   tile 0: element (nt, idx) in v[R_T0 + 2 (16 nt + idx) : +1]
-//     v[R_T1, R_T1 + 32 NT)   tile 1
+//     v[AV, AV+32)        ring of eight 16-byte A-operand reads
+//     v[T0, T0 + 32 NT)   tile 0: element (nt, idx) in v[T0 + 2 (16 nt + idx) : +1]
+//     v[T1, T1 + 32 NT)   tile 1
 // Element idx of pattern group nt holds state 4 idx + (lane >> 4) of pattern lane & 15 -- the C/D and the B lane map
 // of v_mfma_f64_4x4x4_4b_f64.  Since these registers are invisible to the compiler, every asm that loads into them
 // is followed by an explicit s_waitcnt before the first use.
-constexpr int R_CC = 96;    // registers the compiler may allocate
-constexpr int R_AV = 96;
-constexpr int R_T0 = 128;
+// With NT = 1 (256 registers, two waves per SIMD) there is room for more tiles: G receives the columns of the next
+// leaf edge while products run (the gather's L2 round trip hides under MFMA work), and S0, S1 hold the top of the
+// stack of saved sibling products, so that on trees of Sethi-Ullman depth <= 2 no conditional likelihood ever
+// leaves the register file; deeper slots (and every slot with NT = 2) go to the global-memory stack.
+constexpr int N_XCD = 8;  // the launch grid is a multiple of this
+
 template <int NT>
-constexpr int tile_reg(int t) { return R_T0 + t * 32 * NT; }
-template <int NT>
-constexpr int reg_top() { return R_T0 + 2 * 32 * NT; }
+struct Plan {
+#ifdef CRAB_PROF
+    static constexpr int CC = 96;  // the cycle counters need room: one register-resident stack slot less
+#else
+    static constexpr int CC = NT == 1 ? 64 : 96;  // registers the compiler may allocate
+#endif
+    static constexpr int AV = CC;
+    static constexpr int T0 = AV + 32;
+    static constexpr int T1 = T0 + 32 * NT;
+    static constexpr bool HAS_PRE = NT == 1;      // a prefetch tile G for the next leaf edge's columns
+    static constexpr int G = T1 + 32 * NT;
+    static constexpr int S0 = G + (HAS_PRE ? 32 * NT : 0);
+    static constexpr int NSTK = NT == 1 ? (256 - S0) / 32 : 0;  // stack slots held in registers
+    static constexpr int TOP = S0 + 32 * NT * NSTK;
+    static_assert(TOP <= 256, "register plan exceeds the two-waves-per-SIMD budget");
+};
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -136,6 +152,11 @@ template <int X, int Y>
 __device__ __forceinline__ void r_mul()
 {
     asm volatile("v_mul_f64 v[%0:%1], v[%0:%1], v[%2:%3]" ::"n"(X), "n"(X + 1), "n"(Y), "n"(Y + 1));
+}
+template <int D, int S>
+__device__ __forceinline__ void r_copy()
+{
+    asm volatile("v_mov_b64 v[%0:%1], v[%2:%3]" ::"n"(D), "n"(D + 1), "n"(S), "n"(S + 1));
 }
 template <int X>
 __device__ __forceinline__ void r_scale(double sc)
@@ -181,15 +202,27 @@ __device__ __forceinline__ void t_mul()
 {
     t_mul_seq<X, Y>(std::make_integer_sequence<int, 16 * NT>{});
 }
+template <int D, int S, int... I>
+__device__ __forceinline__ void t_copy_seq(std::integer_sequence<int, I...>)
+{
+    (r_copy<D + 2 * I, S + 2 * I>(), ...);
+}
+// D = S, element-wise, NT groups
+template <int NT, int D, int S>
+__device__ __forceinline__ void t_copy()
+{
+    t_copy_seq<D, S>(std::make_integer_sequence<int, 16 * NT>{});
+}
 template <int X, int... I>
 __device__ __forceinline__ void t_scale_seq(double sc, std::integer_sequence<int, I...>)
 {
     (r_scale<X + 2 * I>(sc), ...);
 }
+// childless non-leaf node: ones (or zeros) on the real states, zeros on the padding
 template <int X, int... I>
-__device__ __forceinline__ void t_set_seq(const double (&v)[16], std::integer_sequence<int, I...>)
+__device__ __forceinline__ void t_const_seq(int ones, int g, int n_states, std::integer_sequence<int, I...>)
 {
-    (r_set<X + 2 * I>(v[I]), ...);
+    (r_set<X + 2 * I>((ones && 4 * I + g < n_states) ? 1.0 : 0.0), ...);
 }
 template <int X, int... I>
 __device__ __forceinline__ void t_dot_seq(double &f, const double (&m)[16], std::integer_sequence<int, I...>)
@@ -296,6 +329,7 @@ __device__ __forceinline__ void dma_matrix(const double *Pm, char *lds_buf, int 
 template <int NT, int X, int Y, int GI, int Q>
 __device__ __forceinline__ void gemm_first_half(unsigned lds_addr)
 {
+    constexpr int R_AV = Plan<NT>::AV;
     constexpr int sp = GI >> 2, ic = GI & 3, b = GI & 1;
     if constexpr (GI + 1 < 32) {
         constexpr int sp1 = (GI + 1) >> 2, ic1 = (GI + 1) & 3;
@@ -312,30 +346,74 @@ __device__ __forceinline__ void gemm_first_half(unsigned lds_addr)
 template <int NT, int X, int Y, int GI, int Q>
 __device__ __forceinline__ void gemm_second_half()
 {
+    constexpr int R_AV = Plan<NT>::AV;
     constexpr int sp = GI >> 2, ic = GI & 3, b = GI & 1;
     constexpr int A = R_AV + (b * 4 + Q) * 4 + 2;
     r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp + 1), false>();
     if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp + 1), false>();
     if constexpr (Q + 1 < 4) gemm_second_half<NT, X, Y, GI, Q + 1>();
 }
-template <int NT, int X, int Y, int GI>
-__device__ __forceinline__ void gemm_group(unsigned lds_addr)
+// Vector-memory traffic that rides inside a product, one instruction every second group (= 16*NT MFMAs), so that the
+// wave never queues a burst of loads in front of its MFMAs: the eight LDS-DMA pieces of the next product's operand
+// image in groups 0..14, then (kernels with a prefetch tile) the eight column loads of the next leaf edge in 16..30.
+template <int G>
+struct Ride {
+    const char *dma_src;   // this lane's first 16 bytes of the image to stage, or nullptr
+    char *dma_dst;         // this wave's 8 KiB of the LDS buffer it goes to
+    const char *img;       // gather image of the leaf edge to prefetch (wave-uniform), or nullptr
+    unsigned voff;         // this lane's byte offset in it
+    template <int GI>
+    __device__ __forceinline__ void at() const
+    {
+        if constexpr (GI % 2 == 0 && GI < 16) {
+            if (dma_src) {
+                constexpr int i = GI / 2;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(dma_src + i * 1024), LDS_PTR(dma_dst + i * 1024), 16, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+        } else if constexpr (GI % 2 == 0 && G >= 0) {
+            if (img) {
+                constexpr int q = (GI - 16) / 2;
+                r_gload128<(G >= 0 ? G : 0) + 4 * q, 64 * q>(img, voff);
+            }
+        }
+    }
+};
+template <int NT, int X, int Y, int GI, typename R>
+__device__ __forceinline__ void gemm_group(unsigned lds_addr, const R &ride)
 {
+    ride.template at<GI>();
     gemm_first_half<NT, X, Y, GI, 0>(lds_addr);
     gemm_second_half<NT, X, Y, GI, 0>();
-    if constexpr (GI + 1 < 32) gemm_group<NT, X, Y, GI + 1>(lds_addr);
+    if constexpr (GI + 1 < 32) gemm_group<NT, X, Y, GI + 1>(lds_addr, ride);
 }
-template <int NT, int X, int Y>
-__device__ __forceinline__ void gemm_tile(unsigned lds_addr)
+template <int NT, int X, int Y, typename R>
+__device__ __forceinline__ void gemm_tile(unsigned lds_addr, const R &ride)
 {
+    constexpr int R_AV = Plan<NT>::AV;
     r_lds_read128<R_AV + 0, 0 * 2048>(lds_addr);
     r_lds_read128<R_AV + 4, 1 * 2048>(lds_addr);
     r_lds_read128<R_AV + 8, 2 * 2048>(lds_addr);
     r_lds_read128<R_AV + 12, 3 * 2048>(lds_addr);
-    gemm_group<NT, X, Y, 0>(lds_addr);
+    gemm_group<NT, X, Y, 0>(lds_addr, ride);
     // the hardware does not interlock MFMA results against the VALU / memory instructions that read them next
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
+
+// Build with -DCRAB_PROF to get a per-phase cycle breakdown of the tree walk (s_memtime, summed per wave, printed by
+// launch_prune to stderr).  Diagnostic builds only: scripts/gpu_prof_phases.sh.
+#ifdef CRAB_PROF
+#define PROF_T(i)                                                   \
+    {                                                               \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        w.prof_acc[i] += _t - w.prof_last;                          \
+        w.prof_last = _t;                                           \
+    }
+__device__ unsigned long long *g_prof_buf;
+#else
+#define PROF_T(i)
+#endif
 
 // State of one wave's walk that is not a register tile.
 template <int NT>
@@ -350,11 +428,114 @@ struct Walk {
     const char *gather0;       // gather image of matrix 0
     char *stack;               // this wave's stack area (uniform) ...
     int32_t *stack_e;          // ... and this lane's element of its exponent area
+    int estk[3][NT];           // exponents of the register-resident stack slots (first NSTK used)
     unsigned lane_off8;        // lane * 8
     unsigned lds_a;            // LDS byte address of this lane's A operand inside a tile pair
     char *smem;
     int wave, lane;
+#ifdef CRAB_PROF
+    unsigned long long prof_acc[12], prof_last;
+#endif
 };
+
+// Requests the codes of alignment row `row2` (the leaf edge after the one whose columns were just requested).
+template <int NT>
+__device__ __forceinline__ void request_codes(Walk<NT> &w, int row2)
+{
+    if (row2 >= 0) {
+        const uint8_t *r = w.codes + (size_t)row2 * w.a.n_pat_pad;
+        unsigned code[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
+    }
+}
+
+// Requests P[i][code] for the 16 states of this lane into tile D, from the gather image of matrix `mat` (L2-resident,
+// shared by every workgroup walking this class), with the codes requested one leaf edge ago; then requests the
+// codes of alignment row `row2` for the leaf edge after this one.
+template <int NT, int D>
+__device__ __forceinline__ void issue_leaf(Walk<NT> &w, int mat, int row2)
+{
+    // (readfirstlane: the "s" operand of the loads must be provably wave-uniform)
+    const char *img = w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8);
+    using S8 = std::make_integer_sequence<int, 8>;
+    t_gather_seq<D>(img, w.code_off[0], S8{});
+    if constexpr (NT == 2) t_gather_seq<D + 32>(img, w.code_off[1], S8{});
+    request_codes<NT>(w, row2);
+}
+
+// Saves the running product in tile X in stack slot `slot`: a register tile for the first NSTK slots, global memory
+// beyond.  The exponents of the register slots live in w.estk (compiler registers).
+template <int NT, int X>
+__device__ __forceinline__ void push(Walk<NT> &w, int slot, const int (&eX)[NT])
+{
+    using P = Plan<NT>;
+    constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
+    if constexpr (P::NSTK >= 1)
+        if (slot == 0) {
+            t_copy<NT, P::S0, X>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w.estk[0][nt] = eX[nt];
+            return;
+        }
+    if constexpr (P::NSTK >= 2)
+        if (slot == 1) {
+            t_copy<NT, P::S0 + 32 * NT, X>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w.estk[1][nt] = eX[nt];
+            return;
+        }
+    if constexpr (P::NSTK >= 3)
+        if (slot == 2) {
+            t_copy<NT, P::S0 + 64 * NT, X>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w.estk[2][nt] = eX[nt];
+            return;
+        }
+    int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eX[nt];
+    t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+}
+// Y *= stack[slot]; the dead tile L is the landing zone when the slot is in global memory.
+template <int NT, int Y, int L>
+__device__ __forceinline__ void pop_mul(Walk<NT> &w, int slot, int (&eY)[NT])
+{
+    using P = Plan<NT>;
+    constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
+    if constexpr (P::NSTK >= 1)
+        if (slot == 0) {
+            t_mul<NT, Y, P::S0>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) eY[nt] += w.estk[0][nt];
+            return;
+        }
+    if constexpr (P::NSTK >= 2)
+        if (slot == 1) {
+            t_mul<NT, Y, P::S0 + 32 * NT>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) eY[nt] += w.estk[1][nt];
+            return;
+        }
+    if constexpr (P::NSTK >= 3)
+        if (slot == 2) {
+            t_mul<NT, Y, P::S0 + 64 * NT>();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) eY[nt] += w.estk[2][nt];
+            return;
+        }
+    const int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+    int es[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) es[nt] = se[nt * 64];
+    t_load<NT, L>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+    r_wait_vm0();
+    t_mul<NT, Y, L>();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) eY[nt] += es[nt];
+}
 
 // Runs the program on the current tile X (exponents eX) until a product Y = P X has been executed (returns false:
 // Y is the current tile now and X is free) or the program ends (returns true: X is the root's tile).
@@ -363,93 +544,96 @@ struct Walk {
 template <int NT, int X, int Y>
 __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
 {
-    constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
+    constexpr bool PRE = Plan<NT>::HAS_PRE;
+    constexpr int G = Plan<NT>::G;
     const PruneArgs &a = w.a;
 
     while (w.ip < a.n_ops) {
         const int il = w.ip & 63;
         if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
         const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
-        const int kind = w0 & 3, flags = (w0 >> 2) & 63, slot = w0 >> 8;
+        const int kind = w0 & 3, flags = (w0 >> 2) & 127, slot = w0 >> 9;
         const int mat = __builtin_amdgcn_readlane(w.batch.mat, il);
         const int arg = __builtin_amdgcn_readlane(w.batch.arg, il);
+        int pre_mat = -1, pre_row2 = -1;
+        if constexpr (PRE) {
+            pre_mat = __builtin_amdgcn_readlane(w.batch.pre_mat, il);
+            pre_row2 = __builtin_amdgcn_readlane(w.batch.pre_row2, il);
+        }
         ++w.ip;
+        PROF_T(11)
 
         if (kind == OP_GEMM) {
             // this edge's operand image was requested one product ago; wait for this wave's share of it, and
             // (barrier) for everybody's: all waves have then also left the product that read the other buffer
             r_wait_vm0();
+            PROF_T(1)
             __syncthreads();
-            if (arg >= 0) dma_matrix(a.P + (size_t)arg * P_ELEMS, w.smem + (w.buf ^ 1) * 32768, w.wave, w.lane);
-            gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768);
+            PROF_T(2)
+            Ride<(PRE ? G : -1)> ride;
+            ride.dma_src = arg >= 0 ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
+            ride.dma_dst = w.smem + (w.buf ^ 1) * 32768 + w.wave * 8192;
+            const bool pre_now = PRE && (flags & F_PRE_EARLY);
+            ride.img = pre_now ? w.gather0 + (size_t)pre_mat * (P_ELEMS * 8) : nullptr;
+            ride.voff = w.code_off[0];
+            gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768, ride);
+            if (pre_now) request_codes<NT>(w, pre_row2);
+            PROF_T(3)
             w.buf ^= 1;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) eY[nt] = eX[nt];
-            if (flags & F_POP_MUL) {
-                // X has been consumed: its registers receive the saved sibling product
-                const int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
-                int es[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) es[nt] = se[nt * 64];
-                t_load<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
-                r_wait_vm0();
-                t_mul<NT, Y, X>();
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) eY[nt] += es[nt];
-            }
+            if (flags & F_POP_MUL) pop_mul<NT, Y, X>(w, slot, eY);
+            PROF_T(4)
             if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, Y>(eY);
-            if (flags & F_PUSH) {
-                int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eY[nt];
-                t_store<NT, Y>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
-            }
+            PROF_T(7)
+            if (flags & F_PUSH) push<NT, Y>(w, slot, eY);
+            PROF_T(8)
             return false;
         }
 
         if (kind == OP_LEAF) {
-            // P[i][code] for the 16 states of this lane, from the edge's gather image (L2-resident, shared by every
-            // workgroup walking this class); the codes were requested one leaf edge ago
-            const char *img = w.gather0 + (size_t)mat * (P_ELEMS * 8);
-            using S8 = std::make_integer_sequence<int, 8>;
-            if (flags & F_MUL_PROD) {
-                t_gather_seq<Y>(img, w.code_off[0], S8{});
-                if constexpr (NT == 2) t_gather_seq<Y + 32>(img, w.code_off[1], S8{});
-            } else {
-                t_gather_seq<X>(img, w.code_off[0], S8{});
-                if constexpr (NT == 2) t_gather_seq<X + 32>(img, w.code_off[1], S8{});
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
-            }
-            if (arg >= 0) {
-                const uint8_t *r = w.codes + (size_t)arg * a.n_pat_pad;
-                unsigned code[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
-            }
-            if (arg >= 0)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");  // the columns have landed; the next codes may still fly
-            else
+            if constexpr (PRE) {
+                // the edge's columns were requested into G by an earlier op
                 r_wait_vm0();
-            if (flags & F_MUL_PROD) t_mul<NT, X, Y>();
-        } else {  // OP_CONST: childless non-leaf node
-            double v[16];
+                PROF_T(5)
+                if (flags & F_MUL_PROD) {
+                    t_mul<NT, X, G>();
+                } else {
+                    t_copy<NT, X, G>();
 #pragma unroll
-            for (int idx = 0; idx < 16; ++idx) v[idx] = (arg && 4 * idx + (w.lane >> 4) < a.n_states) ? 1.0 : 0.0;
-            t_set_seq<X>(v, std::make_integer_sequence<int, 16>{});
-            if constexpr (NT == 2) t_set_seq<X + 32>(v, std::make_integer_sequence<int, 16>{});
+                    for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
+                }
+                PROF_T(6)
+            } else {
+                // P[i][code] for the 16 states of this lane, from the edge's gather image (L2-resident, shared by
+                // every workgroup walking this class); the codes were requested one leaf edge ago
+                if (flags & F_MUL_PROD) {
+                    issue_leaf<NT, Y>(w, mat, arg);
+                } else {
+                    issue_leaf<NT, X>(w, mat, arg);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
+                }
+                if (arg >= 0)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");  // the columns have landed; the next codes may still fly
+                else
+                    r_wait_vm0();
+                PROF_T(5)
+                if (flags & F_MUL_PROD) t_mul<NT, X, Y>();
+                PROF_T(6)
+            }
+        } else {  // OP_CONST: childless non-leaf node
+            t_const_seq<X>(arg, w.lane >> 4, a.n_states, std::make_integer_sequence<int, 16>{});
+            if constexpr (NT == 2) t_const_seq<X + 32>(arg, w.lane >> 4, a.n_states, std::make_integer_sequence<int, 16>{});
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
         }
         if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, X>(eX);
-        if (flags & F_PUSH) {
-            int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eX[nt];
-            t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
-        }
+        PROF_T(7)
+        if (flags & F_PUSH) push<NT, X>(w, slot, eX);
+        PROF_T(8)
+        if constexpr (PRE)
+            if (flags & F_PRE_LATE) issue_leaf<NT, G>(w, pre_mat, pre_row2);
     }
     return true;
 }
@@ -481,15 +665,12 @@ __device__ __forceinline__ void root_sum(const PruneArgs &a, const int (&eX)[NT]
 // patterns with two register tiles (see walk()).  The program is per class (matrix indices resolved on the host),
 // so the only dependent global reads on the walk are the leaf-edge column gathers.
 template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void prune_kernel(PruneArgs a, long long n_tiles)
+__device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // two 32 KiB operand images
-    constexpr int X0 = tile_reg<NT>(0), X1 = tile_reg<NT>(1);
+    constexpr int X0 = Plan<NT>::T0, X1 = Plan<NT>::T1;
     // the highest fixed register, named once so that the kernel descriptor allocates the whole plan
-    if constexpr (NT == 1)
-        asm volatile("" ::: "v191");
-    else
-        asm volatile("" ::: "v255");
+    asm volatile("" ::: "v255");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -497,7 +678,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void pr
     const long long n_work = n_tiles * a.K;
     constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
 
-    for (long long wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    // Work items are ordered class-major and cut into one contiguous chunk per XCD (workgroups are dealt round-robin
+    // to the 8 XCDs), so the workgroups sharing an L2 walk the same class's matrices at about the same time.
+    // Placement only matters for speed: any mapping computes every item exactly once.
+#ifdef CRAB_PROF
+    unsigned long long prof_keep[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
+    const long long chunk_lo = n_work * xcd / N_XCD, chunk_hi = n_work * (xcd + 1) / N_XCD;
+    for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
         const int cls = (int)(wi / n_tiles);
         const long long tile = wi - (long long)cls * n_tiles;
         const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
@@ -516,6 +705,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void pr
         w.wave = wave;
         w.lane = lane;
 
+#ifdef CRAB_PROF
+        for (int i = 0; i < 12; ++i) w.prof_acc[i] = prof_keep[i];
+        w.prof_last = __builtin_amdgcn_s_memtime();
+#endif
         int e0[NT], e1[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -531,9 +724,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void pr
             const uint8_t *r = w.codes + (size_t)a.first_leaf_row * a.n_pat_pad;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = (unsigned)r[nt * 16] * 512u + (unsigned)g * 16u;
+            if constexpr (Plan<NT>::HAS_PRE)
+                if (a.first_leaf_op >= 0) issue_leaf<NT, Plan<NT>::G>(w, w.ops[a.first_leaf_op].mat, a.second_leaf_row);
         }
 
         const size_t out0 = (size_t)cls * a.n_pat_pad + pat0;
+        PROF_T(0)
         for (;;) {
             if (walk<NT, X0, X1>(w, e0, e1)) {
                 root_sum<NT, X0>(a, e0, out0, g);
@@ -544,14 +740,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(R_CC))) void pr
                 break;
             }
         }
+#ifdef CRAB_PROF
+        PROF_T(0)
+        for (int i = 0; i < 12; ++i) prof_keep[i] = w.prof_acc[i];
+        if (lane == 0)
+            for (int i = 0; i < 12; ++i) g_prof_buf[((size_t)blockIdx.x * 4 + wave) * 12 + i] = prof_keep[i];
+#endif
     }
+}
+
+// amdgpu_num_vgpr wants a literal: one entry point per tile width
+#ifdef CRAB_PROF
+#define CRAB_CC_NT1 96
+#else
+#define CRAB_CC_NT1 64
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(CRAB_CC_NT1))) void prune_kernel_nt1(PruneArgs a, long long n_tiles)
+{
+    static_assert(Plan<1>::CC == CRAB_CC_NT1, "");
+    prune_body<1>(a, n_tiles);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void prune_kernel_nt2(PruneArgs a, long long n_tiles)
+{
+    static_assert(Plan<2>::CC == 96, "");
+    prune_body<2>(a, n_tiles);
 }
 
 static int g_nt = 0;
 static int chosen_nt()
 {
     if (g_nt == 0) {
-        g_nt = 2;
+        g_nt = 1;
         if (const char *s = std::getenv("CRAB_NT")) {
             const int v = std::atoi(s);
             if (v == 1 || v == 2) g_nt = v;
@@ -566,8 +785,8 @@ static int blocks_per_cu()
     if (g_blocks_per_cu == 0) {
         int occ = 0;
         const hipError_t err = chosen_nt() == 1
-                                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<1>, 256, prune_lds_bytes())
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel<2>, 256, prune_lds_bytes());
+                                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel_nt1, 256, prune_lds_bytes())
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel_nt2, 256, prune_lds_bytes());
         const int want = 2;
         g_blocks_per_cu = (err == hipSuccess && occ >= 1) ? (occ > want ? want : occ) : 1;
         if (const char *s = std::getenv("CRAB_BLOCKS_PER_CU")) {
@@ -588,7 +807,8 @@ int prune_grid_size(int64_t n_work)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int64_t cap = (int64_t)cus * blocks_per_cu();
-    return (int)(n_work < cap ? n_work : cap);
+    const int64_t want = ((n_work + N_XCD - 1) / N_XCD) * N_XCD;  // a multiple of N_XCD: see prune_body
+    return (int)(want < cap ? want : cap);
 }
 
 size_t prune_stack_doubles(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 16 * 64; }
@@ -609,14 +829,14 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
     (void)hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 12 * 4 * 4096, stream);
 #endif
     if (nt == 1)
-        hipLaunchKernelGGL(prune_kernel<1>, dim3(grid), dim3(256), lds, stream, a, n_tiles);
+        hipLaunchKernelGGL(prune_kernel_nt1, dim3(grid), dim3(256), lds, stream, a, n_tiles);
     else
-        hipLaunchKernelGGL(prune_kernel<2>, dim3(grid), dim3(256), lds, stream, a, n_tiles);
+        hipLaunchKernelGGL(prune_kernel_nt2, dim3(grid), dim3(256), lds, stream, a, n_tiles);
 #ifdef CRAB_PROF
     {
         (void)hipStreamSynchronize(stream);
-        static const char *names[12] = {"prologue+root", "gemm wait vmcnt+barrier", "gemm issue dma/prefetch", "gemm mfma", "gemm post (barrier/dma/pop)",
-                                        "leaf wait", "leaf multiply", "normalise", "push", "fin copy+misc", "late prefetch+op advance", "op decode"};
+        static const char *names[12] = {"prologue+root", "gemm wait vmcnt", "gemm barrier", "gemm dma issue + mfma", "gemm pop-mul",
+                                        "leaf gather issue + wait", "leaf multiply", "normalise", "push", "-", "-", "op decode"};
         std::vector<unsigned long long> h((size_t)grid * 4 * 12);
         (void)hipMemcpy(h.data(), d_prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[12] = {0}, all = 0;

@@ -306,3 +306,16 @@ def test_c_and_python_q_builders_agree():
                                    rtol=1e-13, atol=1e-17)
     with pytest.raises(ValueError):
         shim.build_codon_q_matrix_py(2.0, 0.5, pi[:60])
+
+
+# ---------------------------------------------------------------------------------------------
+# register plan of the pruning kernels
+# ---------------------------------------------------------------------------------------------
+def test_compiler_stays_out_of_the_fixed_tile_registers():
+    """The pruning kernels keep their conditional-likelihood tiles in fixed VGPRs above an amdgpu_num_vgpr limit
+    that the allocator treats as a request, not a guarantee: check the generated ISA."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_reserved_vgprs", os.path.join(ROOT, "scripts", "check_reserved_vgprs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.violations() == []
