@@ -259,7 +259,7 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
     }
     // ---- pass 2: stack need per internal node (Sethi-Ullman) ----
     auto is_internal = [&](int v) { return !e->in_leaf_set[v]; };
-    std::vector<int> need(n_nodes, 0);
+    std::vector<int> need(n_nodes, 0), height(n_nodes, 0);  // height: internal levels below the node
     std::vector<std::vector<int>> int_children(n_nodes);
     for (int v : order) {
         if (!is_internal(v)) continue;
@@ -269,9 +269,13 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             if (is_internal(c)) ic.push_back(c);
         }
         std::stable_sort(ic.begin(), ic.end(), [&](int x, int y) { return need[x] > need[y]; });
-        int nd = 0;
-        for (size_t i = 0; i < ic.size(); ++i) nd = std::max(nd, need[ic[i]] + (i > 0 ? 1 : 0));
+        int nd = 0, h = 0;
+        for (size_t i = 0; i < ic.size(); ++i) {
+            nd = std::max(nd, need[ic[i]] + (i > 0 ? 1 : 0));
+            h = std::max(h, height[ic[i]] + 1);
+        }
         need[v] = nd;
+        height[v] = h;
     }
     e->max_depth = need[e->root];
 
@@ -318,7 +322,10 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             any = true;
         }
         if (!any) emit(OP_CONST, v, 0, 1, 0);  // childless non-leaf node: all ones (likelihood.rs:178)
-        e->ops.back().flags |= F_FIN;
+        // A finished node is normalised (power-of-two rescaling, exponent booked) on every second level and at the
+        // root: between two normalisations a conditional likelihood passes through at most two products and a
+        // handful of sibling multiplications, far from the fp64 exponent range even on tiny branches.
+        e->ops.back().flags |= F_FIN | ((height[v] % 2 == 0 || v == e->root) ? F_RESCALE : 0);
         const int depth = f.depth;
         fs.pop_back();
         if (!fs.empty()) {

@@ -45,8 +45,8 @@ enum : int32_t {
     F_MUL_PROD = 1,   // multiply the new term into the running product of this node
     F_POP_MUL = 2,    // multiply the new term with stack[slot] (the product saved before a sibling subtree)
     F_PUSH = 4,       // after this op, save the running product in stack[slot]
-    F_FIN = 8,        // after this op the node is complete: normalise, becomes the operand of the next GEMM
-    F_RESCALE = 16,   // normalise the running product now (long runs of children)
+    F_FIN = 8,        // after this op the node is complete: it becomes the operand of the next GEMM
+    F_RESCALE = 16,   // after this op, normalise the running product (every second tree level; long runs of children)
     // leaf-edge prefetch schedule (used by kernels that keep a prefetch tile): the columns of the next leaf edge are
     // requested while a product runs, or at the end of the op just before that leaf edge
     F_PRE_EARLY = 32, // GEMM: before the product starts, request the columns of leaf edge pre_node

@@ -584,7 +584,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             for (int nt = 0; nt < NT; ++nt) eY[nt] = eX[nt];
             if (flags & F_POP_MUL) pop_mul<NT, Y, X>(w, slot, eY);
             PROF_T(4)
-            if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, Y>(eY);
+            if (flags & F_RESCALE) t_normalise<NT, Y>(eY);
             PROF_T(7)
             if (flags & F_PUSH) push<NT, Y>(w, slot, eY);
             PROF_T(8)
@@ -628,7 +628,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) eX[nt] = 0;
         }
-        if (flags & (F_FIN | F_RESCALE)) t_normalise<NT, X>(eX);
+        if (flags & F_RESCALE) t_normalise<NT, X>(eX);
         PROF_T(7)
         if (flags & F_PUSH) push<NT, X>(w, slot, eX);
         PROF_T(8)

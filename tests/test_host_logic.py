@@ -154,7 +154,7 @@ def test_caterpillar_and_star_trees():
     parent = np.full(n + 1, n, dtype=np.int32)
     parent[n] = -1
     ops, depth = compile_tree(parent, np.arange(n))
-    assert depth == 0 and len(ops) == n and ((ops[:, 2] & 16) != 0).sum() == n // 4
+    assert depth == 0 and len(ops) == n and ((ops[:, 2] & 16) != 0).sum() == n // 4 + 1  # every 4th term, and the root
 
 
 def test_tree_errors_match_reference_behaviour():
