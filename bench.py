@@ -32,6 +32,17 @@ FP64_MFMA_PEAK_TFLOPS = 78.6           # MI355X FP64 matrix peak (AMD CDNA4 data
 N_TAXA, N_SITES, SEED = 100, 10000, 2
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the pruning kernel, from the committed rocprofv3 --pmc passes over this same
+    workload (profiles/r1_pmc_c2.json: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).  A counter
+    run cannot share a process with the timed run, so this is a recorded figure, not a live one; None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_c2.json")) as fh:
+            return float(json.load(fh)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(case, sample_sites=2000, reps=2):
     """The oracle (CPU restatement of the Rust path, reference mode) on a bounded sample of the same workload,
     one thread per site class like the reference's Rayon loop (likelihood.rs:267)."""
@@ -137,8 +148,8 @@ def main():
                        "taxa": N_TAXA, "codons_per_gpu": N_SITES, "patterns_per_gpu": n_pat, "classes": K,
                        "branches": n_branches, "sharding": f"patterns over {world} GPU(s)", "lnL": lnL},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "prune_kernel", "kernel_ms": kernel_ms,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "kernel": "prune_kernel_nt1", "kernel_ms": kernel_ms,
                          "algorithmic_flop_per_launch": dense * FLOP_PER_UPDATE,
                          "dense_updates_per_launch": dense, "gathered_leaf_updates_per_launch": gather},
             "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms,
