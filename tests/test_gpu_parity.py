@@ -397,3 +397,40 @@ def test_edge_cases(gpu_engine_cls, oracle):
             eng.n_states, eng.n_nodes, eng.n_sites = 61, len(bl), 1
             eng.site_classes(Q, pr, pi, bl)
         assert ei.value.status == _lib.CRAB_ERR_STATE
+
+
+def test_deep_stack_register_and_global_slots(gpu_engine_cls, oracle):
+    """A perfectly balanced 64-leaf tree needs 5 saved sibling products at once (Sethi-Ullman depth 5): the first
+    slots live in registers, the rest spill to the global stack.  Both must give the oracle's per-site values."""
+    from crabml_amd import synth
+    from crabml_amd.engine import compile_tree
+    base = synth.make_case("M8", 8, 257, seed=31, mean_branch=0.07)
+    n = 64
+    parent = np.full(2 * n - 1, -1, dtype=np.int32)
+    level, nxt = list(range(n)), n
+    while len(level) > 1:
+        up = []
+        for i in range(0, len(level), 2):
+            parent[level[i]] = parent[level[i + 1]] = nxt
+            up.append(nxt)
+            nxt += 1
+        level = up
+    _, depth = compile_tree(parent, np.arange(n, dtype=np.int32))
+    assert depth == 5
+    rng = np.random.default_rng(5)
+    bl = rng.exponential(0.05, size=len(parent))
+    bl[-1] = 0.0
+    codes = rng.integers(0, 61, size=(n, 257)).astype(np.int32)
+    codes[rng.random(codes.shape) < 0.02] = 64
+    ts = [(v, None if parent[v] < 0 else int(parent[v])) for v in range(len(parent))]
+    with _engine(gpu_engine_cls, parent, codes) as eng:
+        lnL, site = eng.site_classes(base.Q, base.proportions, base.pi, bl, return_sites=True)
+        P_dev = np.stack([eng.export_transition_matrices(k) for k in range(len(base.Q))])
+    # random codes put the weight on near-impossible paths, where P(t)'s tiny entries differ between eigensolvers by
+    # far more than 1e-10 relative: staged comparison (the device's own P(t) through the oracle's pruning), strict
+    lnf = oracle.site_lnf_from_transition_matrices(P_dev, base.pi, ts, codes, np.arange(n, dtype=np.int32))
+    want = _mixture(lnf, base.proportions)
+    assert _rel(site, want) <= SITE_RTOL and abs(lnL - want.sum()) <= TOTAL_ATOL
+    ref = oracle.compute_site_class_log_likelihood(list(base.Q), base.proportions, base.pi, ts, bl, None, codes,
+                                                   np.arange(n, dtype=np.int32))
+    assert abs(lnL - ref) < 1e-3 * 257   # end to end: loose for the reason above
