@@ -110,7 +110,7 @@ struct TreeProgram {
     std::vector<int> parent, child_start, child, leaf_row;
     std::vector<char> in_leaf_set, reachable;
     std::vector<TreeOp> ops;
-    int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1;
+    int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
     int64_t n_gemm_edges = 0, n_leaf_edges = 0;
 };
 
@@ -352,37 +352,59 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             next_gemm_op = i;
         }
     e->first_gemm_op = next_gemm_op;
-    // ---- pass 4: leaf-edge prefetch schedule.  A wave owns one prefetch tile.  The columns of a leaf edge are
-    // requested at the first product (GEMM) after the previous leaf edge was consumed, so that the gather latency
-    // hides under MFMA work, or at the end of the op just before it when no product lies in between. ----
+    // ---- pass 4: leaf-edge prefetch schedule.  A wave owns one prefetch tile G.  The columns of a leaf edge are
+    // requested into G at the first product (GEMM) after the previous leaf edge was consumed, so that the gather
+    // latency hides under MFMA work, or at the end of the op just before it when no product lies in between.
+    // When the two ops after a product are both leaf edges (a cherry, typically), the second one's columns are
+    // requested by the same product into the registers of its dying B operand, which is the landing tile of the
+    // ops that follow.  Codes are queued two leaf edges ahead. ----
     std::vector<int> leaf_ops;
     for (int i = 0; i < (int)e->ops.size(); ++i) {
-        e->ops[i].pre_node = -1;
-        e->ops[i].pre_row2 = -1;
-        if (e->ops[i].kind == OP_LEAF) leaf_ops.push_back(i);
+        TreeOp &op = e->ops[i];
+        op.pre_node = op.pre_node_b = -1;
+        op.pre_row2 = op.pre_row3 = -1;
+        op.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
+        if (op.kind == OP_LEAF) leaf_ops.push_back(i);
     }
-    e->first_leaf_row = leaf_ops.empty() ? -1 : e->ops[leaf_ops[0]].arg;
-    e->second_leaf_row = leaf_ops.size() > 1 ? e->ops[leaf_ops[1]].arg : -1;
-    e->first_leaf_op = (!leaf_ops.empty() && leaf_ops[0] == 0) ? 0 : -1;
-    size_t li = 0;                               // leaf_ops[li] = next leaf edge not yet consumed
-    bool requested = e->first_leaf_op == 0;      // its columns have been requested (the prefetch tile is busy)
-    auto request_at = [&](TreeOp &op, int flag) {
-        op.flags |= flag;
-        op.pre_node = e->ops[leaf_ops[li]].node;
-        op.pre_row2 = li + 1 < leaf_ops.size() ? e->ops[leaf_ops[li + 1]].arg : -1;
-        requested = true;
-    };
+    const int n_leaf = (int)leaf_ops.size();
+    auto leaf_row = [&](int k) { return k < n_leaf ? e->ops[leaf_ops[k]].arg : -1; };
+    e->first_leaf_row = leaf_row(0);
+    e->second_leaf_row = leaf_row(1);
+    e->third_leaf_row = leaf_row(2);
+    e->first_leaf_op = (n_leaf > 0 && leaf_ops[0] == 0) ? 0 : -1;
+    if (!prune_has_prefetch()) return;
+    const int reg_slots = prune_reg_stack_slots();
+    int li = 0;                                  // leaf_ops[li] = next leaf edge not yet consumed
+    int req = e->first_leaf_op == 0 ? 1 : 0;     // how many of the upcoming leaf edges have been requested (0..2)
     for (int i = 0; i < (int)e->ops.size(); ++i) {
         TreeOp &op = e->ops[i];
         const bool next_is_leaf = i + 1 < (int)e->ops.size() && e->ops[i + 1].kind == OP_LEAF;
+        auto request_g = [&](int flag) {   // leaf li + req -> G (req must be 0)
+            op.flags |= flag;
+            op.pre_node = e->ops[leaf_ops[li]].node;
+            op.pre_row2 = leaf_row(li + 2);
+            req = 1;
+        };
         if (op.kind == OP_LEAF) {
-            requested = false;  // consumed here
+            --req;
             ++li;
-            if (next_is_leaf) request_at(op, F_PRE_LATE);
+            if (req == 0 && next_is_leaf) request_g(F_PRE_LATE);
         } else if (op.kind == OP_GEMM) {
-            if (!requested && li < leaf_ops.size()) request_at(op, F_PRE_EARLY);
-        } else if (!requested && next_is_leaf) {
-            request_at(op, F_PRE_LATE);
+            const int head = li + req;  // leaf edge at the head of the code queue before this op
+            if (req == 0 && li < n_leaf) request_g(F_PRE_EARLY);
+            const bool global_pop = (op.flags & F_POP_MUL) && op.slot >= reg_slots;
+            if (req == 1 && next_is_leaf && li + 1 < n_leaf && leaf_ops[li + 1] == i + 2 && (e->ops[i + 2].flags & F_MUL_PROD) &&
+                !global_pop) {
+                op.flags |= F_PRE_DYING;
+                op.pre_node_b = e->ops[i + 2].node;
+                e->ops[i + 2].flags |= F_IN_LANDING;
+                req = 2;
+            }
+            // the requests of this op took 1 or 2 entries off the code queue: refill with the rows that follow
+            op.pre_row2 = leaf_row(head + 2);
+            op.pre_row3 = leaf_row(head + 3);
+        } else if (req == 0 && next_is_leaf) {
+            request_g(F_PRE_LATE);
         }
     }
 }
@@ -407,9 +429,11 @@ void resolve_programs(const TreeProgram *e, int K, const std::vector<int32_t> &p
         for (size_t i = 0; i < n_ops; ++i) {
             const TreeOp &op = e->ops[i];
             DevOp d{};
-            d.w0 = op.kind | (op.flags << 2) | (op.slot << 9);
+            d.w0 = op.kind | (op.flags << 2) | (op.slot << 11);
             d.pre_mat = op.pre_node >= 0 ? pk[op.pre_node] : -1;
+            d.pre_mat_b = op.pre_node_b >= 0 ? pk[op.pre_node_b] : -1;
             d.pre_row2 = op.pre_row2;
+            d.pre_row3 = op.pre_row3;
             d.mat = op.kind == OP_CONST ? 0 : pk[op.node];
             d.arg = op.kind == OP_GEMM ? (op.arg >= 0 ? pk[e->ops[op.arg].node] : -1) : op.kind == OP_LEAF ? next_leaf_row[i] : op.arg;
             out[(size_t)k * stride + i] = d;
@@ -632,6 +656,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.first_leaf_row = e->first_leaf_row;
     pa.first_leaf_op = e->first_leaf_op;
     pa.second_leaf_row = e->second_leaf_row;
+    pa.third_leaf_row = e->third_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));

@@ -50,7 +50,10 @@ enum : int32_t {
     // leaf-edge prefetch schedule (used by kernels that keep a prefetch tile): the columns of the next leaf edge are
     // requested while a product runs, or at the end of the op just before that leaf edge
     F_PRE_EARLY = 32, // GEMM: before the product starts, request the columns of leaf edge pre_node
-    F_PRE_LATE = 64   // any op: at its end, request the columns of leaf edge pre_node (the next op is that leaf edge)
+    F_PRE_LATE = 64,  // any op: at its end, request the columns of leaf edge pre_node (the next op is that leaf edge)
+    F_PRE_DYING = 128,  // GEMM: also request the columns of leaf edge pre_node_b into the registers of the product's B
+                        // operand as they die, k-tile by k-tile; they are then in the landing tile of the ops that follow
+    F_IN_LANDING = 256  // LEAF (with F_MUL_PROD): the columns were requested by the preceding product's F_PRE_DYING
 };
 // The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
 // device form (DevOp, matrix indices) before upload, so the kernel never chases the (class, node) -> matrix table.
@@ -60,17 +63,21 @@ struct TreeOp {
     int32_t flags;   // F_*
     int32_t arg;     // LEAF: alignment row; GEMM: index of the next GEMM op (-1 none); CONST: 1 -> ones, 0 -> zeros
     int32_t slot;    // stack slot for F_PUSH / F_POP_MUL
-    int32_t pre_node;  // F_PRE_*: child node of the leaf edge whose columns are requested
-    int32_t pre_row2;  // F_PRE_*: alignment row of the leaf edge after that one (its codes are requested too), -1 none
+    int32_t pre_node;    // F_PRE_EARLY/LATE: child node of the leaf edge whose columns are requested
+    int32_t pre_node_b;  // F_PRE_DYING: child node of the second leaf edge requested by this op
+    int32_t pre_row2;    // alignment rows whose codes refill the two-deep code queue after the request(s), -1 none:
+    int32_t pre_row3;    //   the leaf edges two (and, with F_PRE_DYING, three) after the first one requested here
 };
 struct alignas(16) DevOp {
-    int32_t w0;        // kind | flags << 2 | slot << 9
+    int32_t w0;        // kind | flags << 2 | slot << 11
     int32_t mat;       // matrix index of this edge in PruneArgs::P
     int32_t arg;       // LEAF: alignment row of the NEXT leaf edge (-1 none); GEMM: matrix of the next GEMM op (-1 none);
                        // CONST: 1 -> ones, 0 -> zeros
-    int32_t pre_mat;   // F_PRE_*: matrix of the leaf edge whose columns are requested
-    int32_t pre_row2;  // F_PRE_*: alignment row whose codes are requested with them (-1 none)
-    int32_t pad[3];
+    int32_t pre_mat;   // F_PRE_EARLY/LATE: matrix of the leaf edge whose columns are requested
+    int32_t pre_row2;  // code-queue refill rows (see TreeOp)
+    int32_t pre_mat_b; // F_PRE_DYING: matrix of the second leaf edge
+    int32_t pre_row3;
+    int32_t pad;
 };
 // Device programs are padded to a multiple of 64 ops plus one extra batch (the kernel reads one batch ahead).
 inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 + 64; }
@@ -101,8 +108,13 @@ struct PruneArgs {
     int32_t first_gemm_op;    // index of the first GEMM op (-1 if none)
     int32_t first_leaf_row;   // alignment row of the first leaf edge in program order (-1 if none)
     int32_t first_leaf_op;    // index of that op if it is op 0 (its columns are requested before the walk starts), else -1
-    int32_t second_leaf_row;  // alignment row of the second leaf edge (-1 if none)
+    int32_t second_leaf_row;  // alignment rows of the second and third leaf edges (-1 if none)
+    int32_t third_leaf_row;
 };
+// Stack slots the configured pruning kernel keeps in registers (the schedule must not park columns in the landing
+// tile of a product that pops a deeper, global-memory slot), and whether it has a prefetch tile at all.
+int prune_reg_stack_slots();
+bool prune_has_prefetch();
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();
 // Number of workgroups launch_prune will use for n_work = tiles*K work items (persistent grid).

@@ -356,28 +356,40 @@ __device__ __forceinline__ void gemm_second_half()
 // Vector-memory traffic that rides inside a product, one instruction every second group (= 16*NT MFMAs), so that the
 // wave never queues a burst of loads in front of its MFMAs: the eight LDS-DMA pieces of the next product's operand
 // image in groups 0..14, then (kernels with a prefetch tile) the eight column loads of the next leaf edge in 16..30.
-template <int G>
+template <int G, int XB>
 struct Ride {
     const char *dma_src;   // this lane's first 16 bytes of the image to stage, or nullptr
     char *dma_dst;         // this wave's 8 KiB of the LDS buffer it goes to
-    const char *img;       // gather image of the leaf edge to prefetch (wave-uniform), or nullptr
+    const char *img;       // gather image of the leaf edge to prefetch into G (wave-uniform), or nullptr
     unsigned voff;         // this lane's byte offset in it
+    const char *img_b;     // gather image of a second leaf edge, prefetched into the B operand tile XB as its
+    unsigned voff_b;       //   k-tiles die (piece q overwrites k-tiles 2q, 2q+1 after group 4q+3 has issued), or nullptr
     template <int GI>
     __device__ __forceinline__ void at() const
     {
-        if constexpr (GI % 2 == 0 && GI < 16) {
+        if constexpr (GI % 2 == 1 && GI < 16) {
             if (dma_src) {
                 constexpr int i = GI / 2;
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(dma_src + i * 1024), LDS_PTR(dma_dst + i * 1024), 16, 0, 0);
                 asm volatile("" ::: "memory");
             }
-        } else if constexpr (GI % 2 == 0 && G >= 0) {
+        } else if constexpr (GI % 2 == 1 && G >= 0) {
             if (img) {
-                constexpr int q = (GI - 16) / 2;
+                constexpr int q = (GI - 17) / 2;
                 r_gload128<(G >= 0 ? G : 0) + 4 * q, 64 * q>(img, voff);
             }
+        } else if constexpr (GI % 4 == 0 && GI >= 4 && G >= 0) {
+            if (img_b) {
+                constexpr int q = GI / 4 - 1;
+                r_gload128<XB + 4 * q, 64 * q>(img_b, voff_b);
+            }
         }
+    }
+    __device__ __forceinline__ void after() const
+    {
+        if constexpr (G >= 0)
+            if (img_b) r_gload128<XB + 28, 64 * 7>(img_b, voff_b);
     }
 };
 template <int NT, int X, int Y, int GI, typename R>
@@ -397,6 +409,7 @@ __device__ __forceinline__ void gemm_tile(unsigned lds_addr, const R &ride)
     r_lds_read128<R_AV + 8, 2 * 2048>(lds_addr);
     r_lds_read128<R_AV + 12, 3 * 2048>(lds_addr);
     gemm_group<NT, X, Y, 0>(lds_addr, ride);
+    ride.after();
     // the hardware does not interlock MFMA results against the VALU / memory instructions that read them next
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
@@ -423,7 +436,8 @@ struct Walk {
     DevOp batch;               // 64 ops, one per lane, decoded with v_readlane
     int ip;                    // next op
     int buf;                   // LDS buffer holding the operand image of the next product
-    unsigned code_off[NT];     // byte offset of the next leaf edge's column inside a gather image, per pattern group
+    unsigned code_off[NT];     // code queue: byte offset of the column inside a gather image, per pattern group, for
+    unsigned code_off2[NT];    //   the next leaf edge whose columns are not requested yet, and the one after it
     const uint8_t *codes;      // this lane's column of the code table
     const char *gather0;       // gather image of matrix 0
     char *stack;               // this wave's stack area (uniform) ...
@@ -438,32 +452,50 @@ struct Walk {
 #endif
 };
 
-// Requests the codes of alignment row `row2` (the leaf edge after the one whose columns were just requested).
+// Byte offset, inside a gather image, of this lane's share of the column its pattern shows in alignment row `row`.
 template <int NT>
-__device__ __forceinline__ void request_codes(Walk<NT> &w, int row2)
+__device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, unsigned (&off)[NT])
 {
-    if (row2 >= 0) {
-        const uint8_t *r = w.codes + (size_t)row2 * w.a.n_pat_pad;
-        unsigned code[NT];
+    const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
+    unsigned code[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+    for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
-    }
+    for (int nt = 0; nt < NT; ++nt) off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
 }
-
+// The code queue holds the offsets of the next two leaf edges whose columns have not been requested yet
+// (code_off, code_off2).  One request took the head: shift, and fetch the codes of alignment row `row` behind it.
+template <int NT>
+__device__ __forceinline__ void refill_codes1(Walk<NT> &w, int row)
+{
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = w.code_off2[nt];
+    if (row >= 0) load_code_offsets<NT>(w, row, w.code_off2);
+}
+// Two requests took both entries.
+template <int NT>
+__device__ __forceinline__ void refill_codes2(Walk<NT> &w, int row_a, int row_b)
+{
+    if (row_a >= 0) load_code_offsets<NT>(w, row_a, w.code_off);
+    if (row_b >= 0) load_code_offsets<NT>(w, row_b, w.code_off2);
+}
 // Requests P[i][code] for the 16 states of this lane into tile D, from the gather image of matrix `mat` (L2-resident,
-// shared by every workgroup walking this class), with the codes requested one leaf edge ago; then requests the
-// codes of alignment row `row2` for the leaf edge after this one.
+// shared by every workgroup walking this class), with the codes at the head of the queue.
 template <int NT, int D>
-__device__ __forceinline__ void issue_leaf(Walk<NT> &w, int mat, int row2)
+__device__ __forceinline__ void issue_columns(Walk<NT> &w, int mat)
 {
     // (readfirstlane: the "s" operand of the loads must be provably wave-uniform)
     const char *img = w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8);
     using S8 = std::make_integer_sequence<int, 8>;
     t_gather_seq<D>(img, w.code_off[0], S8{});
     if constexpr (NT == 2) t_gather_seq<D + 32>(img, w.code_off[1], S8{});
-    request_codes<NT>(w, row2);
+}
+// Kernels without a prefetch tile: columns now, then the codes of the next leaf edge (alignment row `row_next`).
+template <int NT, int D>
+__device__ __forceinline__ void issue_leaf(Walk<NT> &w, int mat, int row_next)
+{
+    issue_columns<NT, D>(w, mat);
+    if (row_next >= 0) load_code_offsets<NT>(w, row_next, w.code_off);
 }
 
 // Saves the running product in tile X in stack slot `slot`: a register tile for the first NSTK slots, global memory
@@ -552,13 +584,15 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
         const int il = w.ip & 63;
         if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
         const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
-        const int kind = w0 & 3, flags = (w0 >> 2) & 127, slot = w0 >> 9;
+        const int kind = w0 & 3, flags = (w0 >> 2) & 511, slot = w0 >> 11;
         const int mat = __builtin_amdgcn_readlane(w.batch.mat, il);
         const int arg = __builtin_amdgcn_readlane(w.batch.arg, il);
-        int pre_mat = -1, pre_row2 = -1;
+        int pre_mat = -1, pre_row2 = -1, pre_mat_b = -1, pre_row3 = -1;
         if constexpr (PRE) {
             pre_mat = __builtin_amdgcn_readlane(w.batch.pre_mat, il);
             pre_row2 = __builtin_amdgcn_readlane(w.batch.pre_row2, il);
+            pre_mat_b = __builtin_amdgcn_readlane(w.batch.pre_mat_b, il);
+            pre_row3 = __builtin_amdgcn_readlane(w.batch.pre_row3, il);
         }
         ++w.ip;
         PROF_T(11)
@@ -570,14 +604,23 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             PROF_T(1)
             __syncthreads();
             PROF_T(2)
-            Ride<(PRE ? G : -1)> ride;
+            Ride<(PRE ? G : -1), X> ride;
             ride.dma_src = arg >= 0 ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
             ride.dma_dst = w.smem + (w.buf ^ 1) * 32768 + w.wave * 8192;
-            const bool pre_now = PRE && (flags & F_PRE_EARLY);
-            ride.img = pre_now ? w.gather0 + (size_t)pre_mat * (P_ELEMS * 8) : nullptr;
+            const bool pre_g = PRE && (flags & F_PRE_EARLY), pre_b = PRE && (flags & F_PRE_DYING);
+            ride.img = pre_g ? w.gather0 + (size_t)pre_mat * (P_ELEMS * 8) : nullptr;
             ride.voff = w.code_off[0];
+            ride.img_b = pre_b ? w.gather0 + (size_t)pre_mat_b * (P_ELEMS * 8) : nullptr;
+            ride.voff_b = pre_g ? w.code_off2[0] : w.code_off[0];
+            // Outside a product a wave is on its latency-bound critical path (gathers, multiplies, barriers) while
+            // the other wave of the SIMD feeds the MFMA pipe: give that path the issue priority (measured +2 %).
+            __builtin_amdgcn_s_setprio(0);
             gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768, ride);
-            if (pre_now) request_codes<NT>(w, pre_row2);
+            __builtin_amdgcn_s_setprio(1);
+            if (pre_g && pre_b)
+                refill_codes2<NT>(w, pre_row2, pre_row3);
+            else if (pre_g || pre_b)
+                refill_codes1<NT>(w, pre_row2);
             PROF_T(3)
             w.buf ^= 1;
 #pragma unroll
@@ -593,10 +636,13 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
 
         if (kind == OP_LEAF) {
             if constexpr (PRE) {
-                // the edge's columns were requested into G by an earlier op
+                // the edge's columns were requested by an earlier op: into G, or by the preceding product into
+                // what is now the landing tile
                 r_wait_vm0();
                 PROF_T(5)
-                if (flags & F_MUL_PROD) {
+                if (flags & F_IN_LANDING) {
+                    t_mul<NT, X, Y>();
+                } else if (flags & F_MUL_PROD) {
                     t_mul<NT, X, G>();
                 } else {
                     t_copy<NT, X, G>();
@@ -633,7 +679,10 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
         if (flags & F_PUSH) push<NT, X>(w, slot, eX);
         PROF_T(8)
         if constexpr (PRE)
-            if (flags & F_PRE_LATE) issue_leaf<NT, G>(w, pre_mat, pre_row2);
+            if (flags & F_PRE_LATE) {
+                issue_columns<NT, G>(w, pre_mat);
+                refill_codes1<NT>(w, pre_row2);
+            }
     }
     return true;
 }
@@ -713,19 +762,21 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             e0[nt] = e1[nt] = 0;
-            w.code_off[nt] = (unsigned)a.n_states * 512u + (unsigned)g * 16u;
+            w.code_off[nt] = w.code_off2[nt] = (unsigned)a.n_states * 512u + (unsigned)g * 16u;
         }
 
         __syncthreads();  // every wave is done reading LDS for the previous work item
+        __builtin_amdgcn_s_setprio(1);
         if (a.first_gemm_op >= 0) dma_matrix(a.P + (size_t)w.ops[a.first_gemm_op].mat * P_ELEMS, smem, wave, lane);
         // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
         w.batch = w.ops[lane];
-        if (a.first_leaf_row >= 0) {
-            const uint8_t *r = w.codes + (size_t)a.first_leaf_row * a.n_pat_pad;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w.code_off[nt] = (unsigned)r[nt * 16] * 512u + (unsigned)g * 16u;
-            if constexpr (Plan<NT>::HAS_PRE)
-                if (a.first_leaf_op >= 0) issue_leaf<NT, Plan<NT>::G>(w, w.ops[a.first_leaf_op].mat, a.second_leaf_row);
+        if (a.first_leaf_row >= 0) load_code_offsets<NT>(w, a.first_leaf_row, w.code_off);
+        if constexpr (Plan<NT>::HAS_PRE) {
+            if (a.second_leaf_row >= 0) load_code_offsets<NT>(w, a.second_leaf_row, w.code_off2);
+            if (a.first_leaf_op >= 0) {
+                issue_columns<NT, Plan<NT>::G>(w, w.ops[a.first_leaf_op].mat);
+                refill_codes1<NT>(w, a.third_leaf_row);
+            }
         }
 
         const size_t out0 = (size_t)cls * a.n_pat_pad + pat0;
@@ -798,6 +849,8 @@ static int blocks_per_cu()
 }
 
 int prune_tile_width() { return 64 * chosen_nt(); }
+int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }
+bool prune_has_prefetch() { return chosen_nt() == 1 ? Plan<1>::HAS_PRE : Plan<2>::HAS_PRE; }
 
 int prune_grid_size(int64_t n_work)
 {
