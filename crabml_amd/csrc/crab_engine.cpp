@@ -104,6 +104,42 @@ double now_ms()
 
 }  // namespace
 
+uint64_t hash_words(const void *p, size_t bytes, uint64_t seed);
+
+// Host cache of spectral decompositions, keyed by the contents of (Q, pi).  Finite-difference gradients perturb one
+// parameter at a time, and a branch-length perturbation changes no rate matrix at all, so most of the K (site classes)
+// or n_nodes (free-ratio) decompositions of a call repeat those of the call before (lib.rs:163-169,387-393 redo all).
+struct EigCache {
+    struct Entry {
+        std::vector<double> Q, pi, eig;
+    };
+    std::unordered_map<uint64_t, std::vector<Entry>> map;
+    size_t count = 0;
+    static constexpr size_t MAX_ENTRIES = 8192;  // x 95 KB
+    const double *find(uint64_t h, const double *Q, const double *pi, int n) const
+    {
+        auto it = map.find(h);
+        if (it == map.end()) return nullptr;
+        for (const Entry &en : it->second)
+            if (std::memcmp(en.Q.data(), Q, sizeof(double) * n * n) == 0 && std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0)
+                return en.eig.data();
+        return nullptr;
+    }
+    void insert(uint64_t h, const double *Q, const double *pi, int n, const double *eig)
+    {
+        if (count >= MAX_ENTRIES) {
+            map.clear();
+            count = 0;
+        }
+        Entry en;
+        en.Q.assign(Q, Q + (size_t)n * n);
+        en.pi.assign(pi, pi + n);
+        en.eig.assign(eig, eig + crab::EIG_STRIDE);
+        map[h].push_back(std::move(en));
+        ++count;
+    }
+};
+
 // The tree compiled for the device: topology tables plus the flat post-order op list.
 struct TreeProgram {
     int n_nodes = 0, root = -1, n_leaf_rows = 0;
@@ -138,6 +174,9 @@ struct crab_engine : TreeProgram {
     DevBuf<int32_t> d_eig_id, d_stack_e, d_e;
     PinBuf<double> h_eig, h_small, h_out;
     PinBuf<int32_t> h_int;
+
+    EigCache eig_cache;
+    int64_t eig_hits = 0, eig_misses = 0;
 
     // ---- last-eval facts ----
     std::vector<int32_t> last_pidx;  // [K][n_nodes] of the last evaluation
@@ -556,7 +595,8 @@ struct EvalPlan {
     int M = 0;                          // transition matrices to build
     std::vector<int32_t> eig_id;        // [M]
     std::vector<double> t_eff;          // [M]
-    int K = 0;                          // classes walked by the pruning kernel
+    int K = 0;                          // classes walked by the pruning kernel (all groups)
+    int n_groups = 1;                   // parameter vectors evaluated together; K / n_groups classes each
     std::vector<int32_t> pidx;          // [K][n_nodes]
     std::vector<double> props;          // [K]
     int mix_mode = MIX_LOGSUMEXP_CLAMP;
@@ -578,15 +618,57 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     const int n = e->n_states;
     HIP_CHECK(hipSetDevice(e->device));
 
-    // ---- host: eigensystems, one task per rate matrix (replaces the serial loop at lib.rs:163-169) ----
+    // ---- host: eigensystems.  Identical rate matrices are decomposed once (within the call and across calls),
+    // the rest in parallel, one task per matrix (replaces the serial loop at lib.rs:163-169) ----
     const double t0 = now_ms();
-    e->h_eig.ensure((size_t)pl.n_eig * EIG_STRIDE);
-    std::vector<char> ok(pl.n_eig, 1);
-    double *h_eig = e->h_eig.p;
     const double *Q = pl.Q;
-    parallel_for(pl.n_eig, [&](int i) { ok[i] = spectral_decompose(n, Q + (size_t)i * n * n, pi, h_eig + (size_t)i * EIG_STRIDE) ? 1 : 0; });
-    for (int i = 0; i < pl.n_eig; ++i)
-        if (!ok[i]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(i));
+    std::vector<int32_t> uniq_of(pl.n_eig);       // rate matrix -> slot among this call's distinct eigensystems
+    std::vector<int> uniq_src;                    // slot -> first rate matrix showing it
+    std::vector<uint64_t> qhash(pl.n_eig);
+    {
+        const uint64_t pih = hash_words(pi, sizeof(double) * n, 11);
+        std::unordered_map<uint64_t, std::vector<int>> seen;
+        for (int i = 0; i < pl.n_eig; ++i) {
+            const double *Qi = Q + (size_t)i * n * n;
+            qhash[i] = hash_words(Qi, sizeof(double) * n * n, pih);
+            auto &cands = seen[qhash[i]];
+            int slot = -1;
+            for (int u : cands)
+                if (std::memcmp(Q + (size_t)uniq_src[u] * n * n, Qi, sizeof(double) * n * n) == 0) {
+                    slot = u;
+                    break;
+                }
+            if (slot < 0) {
+                slot = (int)uniq_src.size();
+                uniq_src.push_back(i);
+                cands.push_back(slot);
+            }
+            uniq_of[i] = slot;
+        }
+    }
+    const int n_uniq = (int)uniq_src.size();
+    e->h_eig.ensure((size_t)n_uniq * EIG_STRIDE);
+    double *h_eig = e->h_eig.p;
+    std::vector<int> todo;
+    for (int u = 0; u < n_uniq; ++u) {
+        const int i = uniq_src[u];
+        if (const double *hit = e->eig_cache.find(qhash[i], Q + (size_t)i * n * n, pi, n))
+            std::memcpy(h_eig + (size_t)u * EIG_STRIDE, hit, sizeof(double) * EIG_STRIDE);
+        else
+            todo.push_back(u);
+    }
+    e->eig_hits += n_uniq - (int)todo.size();
+    e->eig_misses += (int)todo.size();
+    std::vector<char> ok(todo.size(), 1);
+    parallel_for((int)todo.size(), [&](int j) {
+        const int u = todo[j];
+        ok[j] = spectral_decompose(n, Q + (size_t)uniq_src[u] * n * n, pi, h_eig + (size_t)u * EIG_STRIDE) ? 1 : 0;
+    });
+    for (size_t j = 0; j < todo.size(); ++j) {
+        const int u = todo[j], i = uniq_src[u];
+        if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(i));
+        e->eig_cache.insert(qhash[i], Q + (size_t)i * n * n, pi, n, h_eig + (size_t)u * EIG_STRIDE);
+    }
     e->last_eigen_ms = now_ms() - t0;
 
     // ---- uploads ----
@@ -608,9 +690,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
     const size_t n_int = (size_t)pl.M;
     e->h_int.ensure(n_int);
-    std::memcpy(e->h_int.p, pl.eig_id.data(), pl.M * sizeof(int32_t));
+    for (int m = 0; m < pl.M; ++m) e->h_int.p[m] = uniq_of[pl.eig_id[m]];
 
-    e->d_eig.ensure((size_t)pl.n_eig * EIG_STRIDE);
+    e->d_eig.ensure((size_t)n_uniq * EIG_STRIDE);
     e->d_teff.ensure(pl.M);
     e->d_pi.ensure(NS);
     e->d_props.ensure(pl.K);
@@ -622,12 +704,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_stack_e.ensure(prune_stack_ints(grid, e->max_depth));
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
-    e->d_patlnl.ensure(e->n_pat_pad);
-    e->d_partials.ensure(std::max(1, mix_blocks(e->n_pat)));
-    e->d_lnL.ensure(1);
+    const int G = pl.n_groups;
+    e->d_patlnl.ensure((size_t)G * e->n_pat_pad);
+    e->d_partials.ensure((size_t)G * std::max(1, mix_blocks(e->n_pat)));
+    e->d_lnL.ensure(G);
     if (pl.by_class) e->d_byclass.ensure((size_t)e->n_pat * pl.K + 1);
 
-    HIP_CHECK(hipMemcpyAsync(e->d_eig.p, h_eig, (size_t)pl.n_eig * EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_eig.p, h_eig, (size_t)n_uniq * EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_teff.p, hs, pl.M * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_pi.p, hs + pl.M, NS * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_props.p, hs + pl.M + NS, pl.K * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -661,17 +744,18 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     launch_prune(pa, grid, e->stream);
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
-    e->h_out.ensure(1 + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0));
+    e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0));
     if (pl.by_class) {
         launch_by_class(e->d_f.p, e->d_e.p, pl.K, e->n_pat, e->n_pat_pad, pl.clamp ? 1 : 0, e->d_byclass.p, e->stream);
-        HIP_CHECK(hipMemcpyAsync(e->h_out.p + 1, e->d_byclass.p, (size_t)e->n_pat * pl.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_CHECK(hipMemcpyAsync(e->h_out.p + G, e->d_byclass.p, (size_t)e->n_pat * pl.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     } else {
         MixArgs ma{};
         ma.f = e->d_f.p;
         ma.e = e->d_e.p;
         ma.weights = e->d_weights.p;
         ma.props = e->d_props.p;
-        ma.K = pl.K;
+        ma.K = pl.K / G;
+        ma.n_groups = G;
         ma.n_pat = e->n_pat;
         ma.n_pat_pad = e->n_pat_pad;
         ma.mode = pl.mix_mode;
@@ -680,11 +764,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         ma.lnL = e->d_lnL.p;
         if (e->n_pat > 0) {
             launch_mix(ma, e->stream);
-            HIP_CHECK(hipMemcpyAsync(e->h_out.p, e->d_lnL.p, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            HIP_CHECK(hipMemcpyAsync(e->h_out.p, e->d_lnL.p, G * sizeof(double), hipMemcpyDeviceToHost, e->stream));
             if (site_lnl)
-                HIP_CHECK(hipMemcpyAsync(e->h_out.p + 1, e->d_patlnl.p, e->n_pat * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+                HIP_CHECK(hipMemcpyAsync(e->h_out.p + G, e->d_patlnl.p, e->n_pat * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         } else {
-            e->h_out.p[0] = 0.0;
+            for (int g = 0; g < G; ++g) e->h_out.p[g] = 0.0;
         }
     }
     HIP_CHECK(hipEventRecord(e->ev_end, e->stream));
@@ -702,16 +786,17 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
 
     if (pl.by_class) {
-        const double *src = e->h_out.p + 1;
+        const double *src = e->h_out.p + G;
         for (int64_t s = 0; s < e->n_sites; ++s) {
             const int64_t p = e->site_to_pat[s];
             if (p < e->pat_begin || p >= e->pat_end) continue;
             std::memcpy(by_class_out + (size_t)s * pl.K, src + (size_t)(p - e->pat_begin) * pl.K, pl.K * sizeof(double));
         }
     } else {
-        if (lnL) *lnL = e->h_out.p[0];
+        if (lnL)
+            for (int g = 0; g < G; ++g) lnL[g] = e->h_out.p[g];
         if (site_lnl) {
-            const double *src = e->h_out.p + 1;
+            const double *src = e->h_out.p + G;
             for (int64_t s = 0; s < e->n_sites; ++s) {
                 const int64_t p = e->site_to_pat[s];
                 if (p < e->pat_begin || p >= e->pat_end) continue;
@@ -825,6 +910,38 @@ int crab_eval_site_classes(crab_engine *e, int K, const double *Q, const double 
         pl.props.assign(proportions, proportions + K);
         pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
         run_plan(e, pl, pi, lnL, site_lnl, nullptr);
+    });
+}
+
+int crab_eval_site_classes_batch(crab_engine *e, int B, int K, const double *Q, const double *proportions, const double *pi,
+                                 const double *branch_lengths, unsigned flags, double *lnL)
+{
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (B < 1 || K < 1 || !Q || !proportions || !pi || !branch_lengths || !lnL)
+            fail(CRAB_ERR_ARG, "crab_eval_site_classes_batch: bad arguments");
+        const int nn = e->n_nodes;
+        EvalPlan pl;
+        pl.n_groups = B;
+        pl.n_eig = B * K;
+        pl.Q = Q;
+        pl.K = B * K;
+        pl.M = B * K * nn;
+        pl.eig_id.resize(pl.M);
+        pl.t_eff.resize(pl.M);
+        pl.pidx.resize((size_t)pl.K * nn);
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < K; ++k)
+                for (int v = 0; v < nn; ++v) {
+                    const int m = (b * K + k) * nn + v;
+                    pl.eig_id[m] = b * K + k;
+                    pl.t_eff[m] = v == e->root ? 0.0 : branch_lengths[(size_t)b * nn + v];
+                    pl.pidx[m] = m;
+                }
+        pl.props.assign(proportions, proportions + (size_t)B * K);
+        pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
+        run_plan(e, pl, pi, lnL, nullptr, nullptr);
     });
 }
 
@@ -1114,6 +1231,7 @@ std::mutex g_cache_mutex;
 std::list<CacheEntry> g_cache;  // most recent first
 constexpr size_t CACHE_MAX = 8;
 
+}  // namespace
 uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
 {
     const unsigned char *b = (const unsigned char *)p;
@@ -1131,6 +1249,7 @@ uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
     for (; i < bytes; ++i) h = mix64(h, b[i]);
     return mix64(h, bytes);
 }
+namespace {
 
 // Returns a cached engine for this (alignment, tree), creating it on first sight.  The caller holds g_cache_mutex.
 crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents,

@@ -128,17 +128,18 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream);
 // (replaces likelihood.rs:147-165,281-291,328-335,349-370 and branch_site_likelihood.rs:160-170)
 enum : int32_t { MIX_LOGSUMEXP_CLAMP = 0, MIX_LOGSUMEXP_NOCLAMP = 1, MIX_LINEAR = 2 };
 struct MixArgs {
-    const double *f;         // [K][n_pat_pad]
+    const double *f;         // [n_groups][K][n_pat_pad]
     const int32_t *e;
     const double *weights;   // [n_pat_pad] pattern multiplicities (0 on padding)
-    const double *props;     // [K] class proportions / frequencies
-    int32_t K;
+    const double *props;     // [n_groups][K] class proportions / frequencies
+    int32_t K;               // classes per group
+    int32_t n_groups;        // parameter vectors evaluated together (1 for a plain evaluation)
     int64_t n_pat;
     int64_t n_pat_pad;
     int32_t mode;
-    double *pat_lnl;         // [n_pat_pad] per-pattern log-likelihood
-    double *partials;        // [mix_blocks(n_pat)]
-    double *lnL;             // [1]
+    double *pat_lnl;         // [n_groups][n_pat_pad] per-pattern log-likelihood
+    double *partials;        // [n_groups][mix_blocks(n_pat)]
+    double *lnL;             // [n_groups]
 };
 int mix_blocks(int64_t n_pat);
 void launch_mix(const MixArgs &a, hipStream_t stream);

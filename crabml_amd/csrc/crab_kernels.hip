@@ -930,10 +930,17 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return s;  // valid on thread 0
 }
 
+// blockIdx.y = group (one parameter vector of a batched evaluation): classes [y*K, (y+1)*K) with their own proportions
 __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
 {
     __shared__ double red[MIX_THREADS / 64];
     const long long p = (long long)blockIdx.x * MIX_THREADS + threadIdx.x;
+    const size_t grp = blockIdx.y;
+    a.f += grp * a.K * a.n_pat_pad;
+    a.e += grp * a.K * a.n_pat_pad;
+    a.props += grp * a.K;
+    a.pat_lnl += grp * a.n_pat_pad;
+    a.partials += grp * gridDim.x;
     double contrib = 0.0;
     if (p < a.n_pat) {
         double lnf;
@@ -980,6 +987,8 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
 __global__ __launch_bounds__(MIX_THREADS) void final_sum_kernel(const double *partials, int n, double *out)
 {
     __shared__ double red[MIX_THREADS / 64];
+    partials += (size_t)blockIdx.x * n;   // one workgroup per group
+    out += blockIdx.x;
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += MIX_THREADS) v += partials[i];
     const double s = block_sum(v, red);
@@ -992,8 +1001,9 @@ void launch_mix(const MixArgs &a, hipStream_t stream)
 {
     const int nb = mix_blocks(a.n_pat);
     if (nb <= 0) return;
-    hipLaunchKernelGGL(mix_kernel, dim3(nb), dim3(MIX_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(MIX_THREADS), 0, stream, a.partials, nb, a.lnL);
+    const int ng = a.n_groups > 0 ? a.n_groups : 1;
+    hipLaunchKernelGGL(mix_kernel, dim3(nb, ng), dim3(MIX_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(ng), dim3(MIX_THREADS), 0, stream, a.partials, nb, a.lnL);
 }
 
 __global__ __launch_bounds__(256) void by_class_kernel(const double *__restrict__ f, const int32_t *__restrict__ e, int K,

@@ -117,6 +117,27 @@ class Engine:
                                                      site.ctypes.data_as(L.dp) if return_sites else None))
         return (lnL.value, site) if return_sites else lnL.value
 
+    def site_classes_batch(self, Q, proportions, pi, branch_lengths, no_clamp=False):
+        """lnL for B parameter vectors at once: Q [B, K, n, n], proportions [B, K], branch_lengths [B, n_nodes]
+        (pi shared).  Element b equals ``site_classes(Q[b], proportions[b], pi, branch_lengths[b])`` bit for bit."""
+        Q_ = np.ascontiguousarray(np.asarray(Q, dtype=np.float64))
+        n = self.n_states
+        if Q_.ndim != 4 or Q_.shape[2:] != (n, n):
+            raise ValueError(f"Q must have shape (B, K, {n}, {n}), got {Q_.shape}")
+        B, K = Q_.shape[:2]
+        pr = np.ascontiguousarray(np.asarray(proportions, dtype=np.float64))
+        bl = np.ascontiguousarray(np.asarray(branch_lengths, dtype=np.float64))
+        if pr.shape != (B, K):
+            raise ValueError(f"proportions must have shape ({B}, {K}), got {pr.shape}")
+        if bl.shape != (B, self.n_nodes):
+            raise ValueError(f"branch_lengths must have shape ({B}, {self.n_nodes}), got {bl.shape}")
+        pi_, pp = self._pi(pi)
+        out = np.empty(B)
+        self._check(self._lib.crab_eval_site_classes_batch(self._h, B, K, Q_.ctypes.data_as(L.dp), pr.ctypes.data_as(L.dp), pp,
+                                                           bl.ctypes.data_as(L.dp), L.CRAB_FLAG_NO_CLAMP if no_clamp else 0,
+                                                           out.ctypes.data_as(L.dp)))
+        return out
+
     def log_likelihood(self, Q, pi, branch_lengths, **kw):
         return self.site_classes(np.asarray(Q)[None], [1.0], pi, branch_lengths, **kw)
 

@@ -85,6 +85,14 @@ int64_t crab_n_sites(const crab_engine *e);
 int crab_eval_site_classes(crab_engine *e, int K, const double *Q, const double *proportions, const double *pi,
                            const double *branch_lengths, unsigned flags, double *lnL, double *site_lnl);
 
+/* B parameter vectors in one launch sequence: lnL[b] for b in [0, B), each as crab_eval_site_classes would give it
+ * (bit-identical).  Q: [B][K][n][n]; proportions: [B][K]; branch_lengths: [B][n_nodes]; pi is shared.
+ * Replaces the n_params+1 sequential FFI calls behind every finite-difference gradient of the reference's
+ * optimisers (scipy L-BFGS-B without jac, optimize/optimizer.py:1197-1203 -> lib.rs:146-191 once per perturbation);
+ * rate matrices that repeat within the batch (branch-length perturbations repeat all of them) are decomposed once. */
+int crab_eval_site_classes_batch(crab_engine *e, int B, int K, const double *Q, const double *proportions,
+                                 const double *pi, const double *branch_lengths, unsigned flags, double *lnL);
+
 /* compute_site_log_likelihoods_by_class (lib.rs:214-258 -> likelihood.rs:303-338):
  * out[s*K + k] = ln max(f_{k,s}, 1e-300), shape [n_sites][K]. */
 int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const double *pi,

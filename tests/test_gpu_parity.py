@@ -434,3 +434,25 @@ def test_deep_stack_register_and_global_slots(gpu_engine_cls, oracle):
     ref = oracle.compute_site_class_log_likelihood(list(base.Q), base.proportions, base.pi, ts, bl, None, codes,
                                                    np.arange(n, dtype=np.int32))
     assert abs(lnL - ref) < 1e-3 * 257   # end to end: loose for the reason above
+
+
+def test_batched_parameter_vectors_equal_single_evaluations(gpu_engine_cls):
+    """crab_eval_site_classes_batch: a finite-difference stencil (branch lengths and kappa/omega perturbed one at a
+    time) in one launch sequence gives, element for element, the bits of the single evaluations."""
+    from crabml_amd import models, synth
+    case = synth.make_case("M8", 20, 700, seed=41)
+    B = 7
+    Q = np.repeat(case.Q[None], B, axis=0).copy()
+    pr = np.repeat(np.asarray(case.proportions)[None], B, axis=0).copy()
+    bl = np.repeat(case.branch_lengths[None], B, axis=0).copy()
+    for b in range(1, 5):
+        bl[b, 3 * b] *= 1.0 + 1e-6            # branch-length perturbations: no new rate matrix
+    m = models.M8CodonModel(kappa=case.kappa * (1 + 1e-6), p0=0.9, p_beta=0.7, q_beta=1.5, omega_s=2.5, ncatG=10, pi=case.pi)
+    Q[5] = np.stack(m.get_Q_matrices())
+    pr[6] = pr[6][::-1] / pr[6].sum()         # a different mixture on the same matrices
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        got = eng.site_classes_batch(Q, pr, case.pi, bl)
+        want = np.array([eng.site_classes(Q[b], pr[b], case.pi, bl[b]) for b in range(B)])
+        again = eng.site_classes_batch(Q, pr, case.pi, bl)
+    assert np.array_equal(got, want) and np.array_equal(got, again)
+    assert len(set(got.tolist())) >= 6        # the perturbations are visible
