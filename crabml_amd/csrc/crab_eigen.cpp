@@ -77,9 +77,10 @@ static void tridiagonalise(int n, double *a, double *d, double *e)
     }
 }
 
-static bool ql_implicit(int n, double *d, double *e, double *z)
+// zt holds the eigenvector matrix transposed (row i = vector i), so that a plane rotation of vectors i and i+1 --
+// the O(n^3) part of the whole decomposition -- runs over two contiguous rows.
+static bool ql_implicit(int n, double *d, double *e, double *zt)
 {
-    auto Z = [&](int i, int j) -> double & { return z[(size_t)i * n + j]; };
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     const double eps = 2.220446049250313e-16;
@@ -112,10 +113,11 @@ static bool ql_implicit(int n, double *d, double *e, double *z)
                     r = (d[i] - g) * s + 2.0 * c * b;
                     d[i + 1] = g + (p = s * r);
                     g = c * r - b;
+                    double *__restrict z0 = zt + (size_t)i * n, *__restrict z1 = zt + (size_t)(i + 1) * n;
                     for (int k = 0; k < n; ++k) {
-                        f = Z(k, i + 1);
-                        Z(k, i + 1) = s * Z(k, i) + c * f;
-                        Z(k, i) = c * Z(k, i) - s * f;
+                        const double f1 = z1[k], f0 = z0[k];
+                        z1[k] = s * f0 + c * f1;
+                        z0[k] = c * f0 - s * f1;
                     }
                 }
                 if (r == 0.0 && i >= l) continue;
@@ -134,7 +136,14 @@ bool symmetric_eigen(int n, double *a, double *d)
     for (int i = 0; i < n; ++i)  // symmetrise from the lower triangle
         for (int j = i + 1; j < n; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i];
     tridiagonalise(n, a, d, e.data());
-    return ql_implicit(n, d, e.data(), a);
+    auto transpose = [&] {
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) std::swap(a[(size_t)i * n + j], a[(size_t)j * n + i]);
+    };
+    transpose();
+    const bool ok = ql_implicit(n, d, e.data(), a);
+    transpose();
+    return ok;
 }
 
 bool spectral_decompose_plain(int n, const double *Q, const double *pi, double *U, double *lam, double *Uinv)

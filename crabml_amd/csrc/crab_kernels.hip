@@ -1,15 +1,16 @@
 // gfx950 (MI355X / CDNA4) kernels of the codon-likelihood engine.
 //
-//   build_p_kernel   batched P(t) = U diag(exp(lam t)) U^-1 on fp64 MFMA, written in MFMA operand order
-//   prune_kernel     Felsenstein pruning: one workgroup walks the whole tree for a tile of site
-//                    patterns and one site class; conditional likelihoods live in registers, every
-//                    internal edge is a 64x64 fp64 MFMA product whose accumulator is the next
-//                    product's B operand; leaf edges are column gathers; child products and
-//                    power-of-two rescaling are fused; P matrices stream through LDS by LDS-DMA
-//   mix_kernel       per-pattern class mixture, log, pattern-weighted deterministic sum
+//   build_p_kernel      batched P(t) = U diag(exp(lam t)) U^-1 on fp64 MFMA, written in the two images of crab_kernels.h
+//   prune_kernel_nt1/2  Felsenstein pruning: one workgroup = 64*NT site patterns of one site class, each wave walks
+//                       the whole tree program for its 16*NT patterns.  Conditional likelihoods live in fixed
+//                       registers outside the compiler's allocation; every internal edge is a 64x64 fp64 MFMA
+//                       product whose accumulator tile is the next product's B operand; leaf edges are column
+//                       gathers prefetched under the products; sibling products are saved in register tiles;
+//                       power-of-two rescaling is fused; P operand images stream through LDS by LDS-DMA
+//   mix_kernel          per-pattern class mixture, log, pattern-weighted deterministic sum (per parameter vector)
 //
-// fp64 MFMA shape: the pruning products use v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X
-// (scripts/micro/): it sustains 64-72 TFLOP/s against 35-49 TFLOP/s for v_mfma_f64_16x16x4_f64, and its
+// fp64 MFMA shape: the pruning products use v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (scripts/micro/,
+// profiles/r1_micro_*): it sustains 73-76 TFLOP/s against 35-49 TFLOP/s for v_mfma_f64_16x16x4_f64, and its
 // D lane map equals its B lane map, so products chain through registers.
 // Written for gfx950 wave64 only.  No other architecture is supported.
 #include "crab_kernels.h"
