@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fd-batch", type=int, default=0,
+                    help="also time crab_eval_site_classes_batch with this many perturbed vectors per call (auxiliary line; "
+                         "off by default so that a rocprofv3 --stats run of the default command averages single evaluations only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,10 +169,10 @@ def main():
             "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms,
                              "host_eigen": float(np.mean(eigen_ms))},
         }
-        if world == 1:
-            # the same hot path used the way a finite-difference gradient uses it: 8 parameter vectors
+        if world == 1 and args.fd_batch > 0:
+            # the same hot path used the way a finite-difference gradient uses it: B parameter vectors
             # per launch sequence, branch lengths perturbed one at a time, through crab_eval_site_classes_batch
-            B = 8
+            B = args.fd_batch
             Qb = np.repeat(Qs[-1][None], B, axis=0)
             prb = np.repeat(np.asarray(case.proportions)[None], B, axis=0)
             blb = np.repeat(case.branch_lengths[None], B, axis=0).copy()
@@ -181,7 +184,7 @@ def main():
             for _ in range(reps):
                 eng.site_classes_batch(Qb, prb, case.pi, blb)
             out["batched_fd"] = {"lnl_evals_per_s": B * reps / (time.perf_counter() - tb), "batch": B,
-                                 "note": "auxiliary, not the headline: 8 perturbed branch-length vectors per call"}
+                                 "note": "auxiliary, not the headline: perturbed branch-length vectors, one call per batch"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case)
         print(json.dumps(out), flush=True)
