@@ -20,60 +20,78 @@ namespace crab {
 // ---------------------------------------------------------------------------------------------
 static void tridiagonalise(int n, double *a, double *d, double *e)
 {
-    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };
-    for (int i = n - 1; i > 0; --i) {
-        const int l = i - 1;
-        double h = 0.0;
-        if (l > 0) {
-            double scale = 0.0;
-            for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
-            if (scale == 0.0) {
-                e[i] = A(i, l);
-            } else {
-                for (int k = 0; k <= l; ++k) {
-                    A(i, k) /= scale;
-                    h += A(i, k) * A(i, k);
-                }
-                double f = A(i, l);
-                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
-                e[i] = scale * g;
-                h -= f * g;
-                A(i, l) = f - g;
-                f = 0.0;
-                for (int j = 0; j <= l; ++j) {
-                    A(j, i) = A(i, j) / h;
-                    g = 0.0;
-                    for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
-                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
-                    e[j] = g / h;
-                    f += e[j] * A(i, j);
-                }
-                const double hh = f / (h + h);
-                for (int j = 0; j <= l; ++j) {
-                    f = A(i, j);
-                    e[j] = g = e[j] - hh * f;
-                    for (int k = 0; k <= j; ++k) A(j, k) -= f * e[k] + g * A(i, k);
-                }
-            }
-        } else {
-            e[i] = A(i, l);
+    // Householder reduction A = Q T Q^T on full symmetric storage, every inner loop over a contiguous row
+    // (the textbook lower-triangle form walks columns; at n = 61 that, not the QL iteration, dominated the
+    // decomposition).  On exit a = Q, d = diag(T), e[i] = T[i][i-1] (e[0] = 0).
+    std::vector<double> V((size_t)n * n, 0.0), beta(n, 0.0), p(n), w(n), t(n);
+    for (int k = 0; k + 2 < n; ++k) {
+        double *rowk = a + (size_t)k * n;
+        d[k] = rowk[k];
+        const int m = n - k - 1;
+        const double *x = rowk + k + 1;
+        // the reflector is invariant under scaling of x: work on x / max|x| so that columns of any magnitude
+        // (a site class with omega ~ 1e-100 has them) neither underflow nor overflow in the squares
+        double scale = 0.0;
+        for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(x[i]));
+        if (scale == 0.0) {
+            e[k + 1] = 0.0;
+            continue;
         }
-        d[i] = h;
+        double *v = &V[(size_t)k * n];
+        double sigma = 0.0;
+        for (int i = 0; i < m; ++i) {
+            v[i] = x[i] / scale;
+            sigma += v[i] * v[i];
+        }
+        const double x0 = v[0], norm = std::sqrt(sigma);
+        const double alpha = x0 >= 0.0 ? -norm : norm;
+        v[0] -= alpha;
+        const double vv = sigma - x0 * x0 + v[0] * v[0];
+        const double bk = 2.0 / vv;
+        beta[k] = bk;
+        double *sub = a + (size_t)(k + 1) * n + (k + 1);
+        for (int i = 0; i < m; ++i) {
+            const double *row = sub + (size_t)i * n;
+            double sdot = 0.0;
+            for (int j = 0; j < m; ++j) sdot += row[j] * v[j];
+            p[i] = bk * sdot;
+        }
+        double pv = 0.0;
+        for (int i = 0; i < m; ++i) pv += p[i] * v[i];
+        const double c = 0.5 * bk * pv;
+        for (int i = 0; i < m; ++i) w[i] = p[i] - c * v[i];
+        for (int i = 0; i < m; ++i) {
+            double *row = sub + (size_t)i * n;
+            const double vi = v[i], wi = w[i];
+            for (int j = 0; j < m; ++j) row[j] -= vi * w[j] + wi * v[j];
+        }
+        e[k + 1] = alpha * scale;
     }
-    d[0] = 0.0;
     e[0] = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const int l = i - 1;
-        if (d[i] != 0.0) {
-            for (int j = 0; j <= l; ++j) {
-                double g = 0.0;
-                for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
-                for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
-            }
+    if (n >= 2) {
+        d[n - 2] = a[(size_t)(n - 2) * n + (n - 2)];
+        e[n - 1] = a[(size_t)(n - 1) * n + (n - 2)];
+    }
+    d[n - 1] = a[(size_t)(n - 1) * n + (n - 1)];
+    // Q = H_0 H_1 ... H_{n-3}, accumulated backwards so that step k only touches the trailing block
+    for (size_t i = 0; i < (size_t)n * n; ++i) a[i] = 0.0;
+    for (int i = 0; i < n; ++i) a[(size_t)i * n + i] = 1.0;
+    for (int k = n - 3; k >= 0; --k) {
+        if (beta[k] == 0.0) continue;
+        const int m = n - k - 1;
+        const double *v = &V[(size_t)k * n];
+        double *sub = a + (size_t)(k + 1) * n + (k + 1);
+        for (int j = 0; j < m; ++j) t[j] = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const double *row = sub + (size_t)i * n;
+            const double vi = v[i];
+            for (int j = 0; j < m; ++j) t[j] += vi * row[j];
         }
-        d[i] = A(i, i);
-        A(i, i) = 1.0;
-        for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+        for (int i = 0; i < m; ++i) {
+            double *row = sub + (size_t)i * n;
+            const double bv = beta[k] * v[i];
+            for (int j = 0; j < m; ++j) row[j] -= bv * t[j];
+        }
     }
 }
 
@@ -101,7 +119,9 @@ static bool ql_implicit(int n, double *d, double *e, double *zt)
                 for (i = m - 1; i >= l; --i) {
                     double f = s * e[i];
                     const double b = c * e[i];
-                    e[i + 1] = r = std::hypot(f, g);
+                    r = std::sqrt(f * f + g * g);  // std::hypot costs more than the rotation it guards: use it only off the safe range
+                    if (!(r > 1e-140 && r < 1e140)) r = std::hypot(f, g);
+                    e[i + 1] = r;
                     if (r == 0.0) {
                         d[i + 1] -= p;
                         e[m] = 0.0;

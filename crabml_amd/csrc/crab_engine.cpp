@@ -627,10 +627,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     std::vector<uint64_t> qhash(pl.n_eig);
     {
         const uint64_t pih = hash_words(pi, sizeof(double) * n, 11);
+        parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
         std::unordered_map<uint64_t, std::vector<int>> seen;
         for (int i = 0; i < pl.n_eig; ++i) {
             const double *Qi = Q + (size_t)i * n * n;
-            qhash[i] = hash_words(Qi, sizeof(double) * n * n, pih);
             auto &cands = seen[qhash[i]];
             int slot = -1;
             for (int u : cands)

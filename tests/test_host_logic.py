@@ -319,3 +319,14 @@ def test_compiler_stays_out_of_the_fixed_tile_registers():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.violations() == []
+
+
+def test_spectral_decomposition_of_every_fixture_matrix():
+    """Includes M7/M8a classes whose omega is ~1e-100 (columns of the symmetrised matrix 50 orders of magnitude apart)."""
+    from crabml_amd.engine import spectral_decompose
+    from util import SITE_MODEL_CASES
+    for name in list(SITE_MODEL_CASES) + ["lysozymeLarge_modelA"]:
+        c = load_case(name)
+        for Q in c["Q"]:
+            U, lam, Ui = spectral_decompose(Q, c["pi"])
+            assert np.abs((U * lam) @ Ui - Q).max() <= 1e-13 * np.abs(Q).max(), name
