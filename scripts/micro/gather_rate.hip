@@ -21,9 +21,10 @@ __global__ __launch_bounds__(256) void k(const char *imgs, const unsigned char *
         if (V == 1) off = code * 512 + g * 128;         // piece q at +16q  (lane-contiguous 128 B)
         if (V == 2) off = lane * 16;                    // piece q at +1024q (fully coalesced, no gather)
         if (V == 3) off = (code & 0) * 512 + g * 16;    // every pattern the same column
+        if (V == 4) off = codes[((size_t)(wave_global % 64) * 997 + r) * 16 % 65536 + (lane >> 2)] * 512 + (lane & 3) * 16;  // quad = one pattern
         v2d v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *(const v2d *)(img + off + q * (V == 0 || V == 3 ? 64 : V == 1 ? 16 : 1024));
+        for (int q = 0; q < 8; ++q) v[q] = *(const v2d *)(img + off + q * (V == 0 || V == 3 || V == 4 ? 64 : V == 1 ? 16 : 1024));
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc += v[q][0] + v[q][1];
     }
@@ -62,5 +63,6 @@ int main()
     run<1>("lane-contiguous 128 B", imgs, codes, out, n_img);
     run<2>("fully coalesced (reference)", imgs, codes, out, n_img);
     run<3>("one column for all patterns", imgs, codes, out, n_img);
+    run<4>("quad of lanes = one 64 B segment", imgs, codes, out, n_img);
     return 0;
 }
