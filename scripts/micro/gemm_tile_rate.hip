@@ -4,15 +4,17 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I crabml_amd/csrc scripts/micro/gemm_tile_rate.hip -o /tmp/gtr && /tmp/gtr
 #include "../../crabml_amd/csrc/crab_kernels.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 using namespace crab;
 
 struct NoRide {
     template <int GI>
     __device__ __forceinline__ void at() const {}
+    __device__ __forceinline__ void after() const {}
 };
 
-template <int NT, int WPS>
+template <int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(double *out, const double *img, int reps)
 {
     constexpr int X = Plan<2>::T0, Y = Plan<2>::T1;   // the NT = 2 plan has room for either width
@@ -22,19 +24,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(do
     for (int i = threadIdx.x; i < 4096; i += 256) ((double *)smem)[i] = img[i];
     __syncthreads();
     const unsigned lds_a = (unsigned)(size_t)LDS_PTR(smem) + (g * 4 + (lane & 3)) * 16;
-    const double seed = 1.0 + 0.001 * threadIdx.x;
+    const double seed = 1.0 + 0.001 * threadIdx.x + 1e-7 * (threadIdx.x * 2654435761u % 1000003u);
     t_scale_seq<X>(0.0, std::make_integer_sequence<int, 16 * NT>{});   // whatever was there: finite or not, timing only
-    asm volatile("v_mov_b64 v[%0:%1], %2" ::"n"(X), "n"(X + 1), "v"(seed));
-    for (int r = 0; r < reps; r += 2) {   // ping-pong, like the walk
-        gemm_tile<NT, X, Y>(lds_a, NoRide{});
-        gemm_tile<NT, Y, X>(lds_a, NoRide{});
+    t_const_seq<X>(1, 0, 64, std::make_integer_sequence<int, 16 * NT>{});
+    t_scale_seq<X>(seed, std::make_integer_sequence<int, 16 * NT>{});
+    if (MODE == 0) {
+        for (int r = 0; r < reps; r += 2) {   // ping-pong, like the walk
+            gemm_tile<NT, X, Y>(lds_a, NoRide{});
+            gemm_tile<NT, Y, X>(lds_a, NoRide{});
+        }
+    } else {
+        // MODE 1: the kernel's Ride hooks with nothing to do; MODE 2: with the LDS-DMA of an image riding along
+        // (into the upper half of a 64 KiB allocation); MODE 3: plus a barrier per product
+        Ride<-1, X> ra;
+        Ride<-1, Y> rb;
+        const int wave = threadIdx.x >> 6;
+        ra.dma_src = rb.dma_src = MODE >= 2 ? (const char *)img + wave * 8192 + lane * 16 : nullptr;
+        ra.dma_dst = rb.dma_dst = smem + 32768 + wave * 8192;
+        ra.img = rb.img = ra.img_b = rb.img_b = nullptr;
+        ra.voff = rb.voff = ra.voff_b = rb.voff_b = 0;
+        for (int r = 0; r < reps; r += 2) {
+            if (MODE >= 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            gemm_tile<NT, X, Y>(lds_a, ra);
+            if (MODE >= 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            gemm_tile<NT, Y, X>(lds_a, rb);
+        }
     }
     double s = 0.0;
     r_fma_into<X>(s, seed);
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NT, int WPS>
+template <int NT, int MODE>
 void run(int blocks_per_cu)
 {
     const int grid = 256 * blocks_per_cu, reps = 400;
@@ -42,20 +63,24 @@ void run(int blocks_per_cu)
     (void)hipMalloc(&out, sizeof(double) * grid * 256);
     (void)hipMalloc(&img, sizeof(double) * 4096);
     std::vector<double> h(4096, 1.0 / 64);
+    if (getenv("RANDOM_DATA")) {   // operand bits matter: the chip holds a lower clock on random mantissas than on constants
+        srand(7);
+        for (auto &x : h) x = (0.5 + rand() / (double)RAND_MAX) / 64.0;
+    }
     (void)hipMemcpy(img, h.data(), sizeof(double) * 4096, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<NT, WPS>), dim3(grid), dim3(256), 32768, 0, out, img, reps);
+    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NT, WPS>), dim3(grid), dim3(256), 32768, 0, out, img, reps);
+    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)grid * 4 * reps * NT * 256 * 512.0;
-    printf("gemm_tile NT=%d waves/SIMD=%d: %.3f ms  %.2f TFLOP/s (64-padded)  %.1f cycles/MFMA/SIMD @2.4GHz\n", NT, blocks_per_cu, ms, flop / ms / 1e9,
+    printf("gemm_tile NT=%d mode=%d waves/SIMD=%d: %.3f ms  %.2f TFLOP/s (64-padded)  %.1f cycles/MFMA/SIMD @2.4GHz\n", NT, MODE, blocks_per_cu, ms, flop / ms / 1e9,
            ms * 1e-3 * 2.4e9 / ((double)reps * NT * 256 * blocks_per_cu));
     (void)hipFree(out);
     (void)hipFree(img);
@@ -63,7 +88,7 @@ void run(int blocks_per_cu)
 
 int main()
 {
-    run<1, 2>(1); run<1, 2>(2);
-    run<2, 2>(1); run<2, 2>(2);
+    run<1, 0>(1); run<1, 0>(2); run<1, 1>(2); run<1, 2>(2); run<1, 3>(2);
+    run<2, 0>(1); run<2, 0>(2); run<2, 1>(2); run<2, 2>(2); run<2, 3>(2);
     return 0;
 }
