@@ -115,7 +115,7 @@ struct EigCache {
     };
     std::unordered_map<uint64_t, std::vector<Entry>> map;
     size_t count = 0;
-    static constexpr size_t MAX_ENTRIES = 8192;  // x 95 KB
+    static constexpr size_t MAX_ENTRIES = 4096;  // x 95 KB = 390 MB at most, then the cache starts over
     const double *find(uint64_t h, const double *Q, const double *pi, int n) const
     {
         auto it = map.find(h);
@@ -159,6 +159,7 @@ struct crab_engine : TreeProgram {
     // ---- tree ----
     bool have_tree = false;
     std::vector<DevOp> dev_ops;  // [K][n_ops_pad] programs as last uploaded
+    std::vector<int32_t> dev_pidx;  // the (class, node) -> matrix table they were resolved with
 
     // ---- alignment ----
     bool have_aln = false;
@@ -664,18 +665,17 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         const int u = todo[j];
         ok[j] = spectral_decompose(n, Q + (size_t)uniq_src[u] * n * n, pi, h_eig + (size_t)u * EIG_STRIDE) ? 1 : 0;
     });
-    for (size_t j = 0; j < todo.size(); ++j) {
-        const int u = todo[j], i = uniq_src[u];
-        if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(i));
-        e->eig_cache.insert(qhash[i], Q + (size_t)i * n * n, pi, n, h_eig + (size_t)u * EIG_STRIDE);
-    }
+    for (size_t j = 0; j < todo.size(); ++j)
+        if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(uniq_src[todo[j]]));
+    // (the new decompositions enter the cache further down, while the device is busy)
     e->last_eigen_ms = now_ms() - t0;
 
     // ---- uploads ----
-    {
+    if (e->dev_ops.empty() || pl.pidx != e->dev_pidx) {   // the programs depend on the tree and on this table only
         std::vector<DevOp> progs;
         resolve_programs(e, pl.K, pl.pidx, progs);
-        if (progs.size() != e->dev_ops.size() || std::memcmp(progs.data(), e->dev_ops.data(), progs.size() * sizeof(DevOp)) != 0) {
+        e->dev_pidx = pl.pidx;
+        {
             e->d_ops.ensure(progs.size());
             HIP_CHECK(hipMemcpyAsync(e->d_ops.p, progs.data(), progs.size() * sizeof(DevOp), hipMemcpyHostToDevice, e->stream));
             HIP_CHECK(hipStreamSynchronize(e->stream));  // progs is pageable
@@ -772,6 +772,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     }
     HIP_CHECK(hipEventRecord(e->ev_end, e->stream));
+    // host work that can hide behind the device: remember the decompositions made for this call
+    for (int u : todo) {
+        const int i = uniq_src[u];
+        e->eig_cache.insert(qhash[i], Q + (size_t)i * n * n, pi, n, h_eig + (size_t)u * EIG_STRIDE);
+    }
     HIP_CHECK(hipStreamSynchronize(e->stream));
     HIP_CHECK(hipGetLastError());
     float ms = 0.f;
