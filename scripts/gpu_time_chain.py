@@ -14,7 +14,7 @@ parent = np.full(3 + L, -1, dtype=np.int32)
 parent[0] = parent[1] = 2
 for v in range(2, 2 + L):
     parent[v] = v + 1
-bl = np.full(3 + L, 0.02)
+bl = np.full(3 + L, float(os.environ.get('CHAIN_T', '0.02')))
 with Engine(0) as eng:
     eng.set_tree(parent, np.arange(2, dtype=np.int32))
     eng.set_alignment(codes, n_states=61, compress=False)
