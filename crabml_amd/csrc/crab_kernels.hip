@@ -15,6 +15,7 @@
 // Written for gfx950 wave64 only.  No other architecture is supported.
 #include "crab_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -415,6 +416,11 @@ __device__ __forceinline__ void gemm_tile(unsigned lds_addr, const R &ride)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
+// Build with -DCRAB_CLOCK to measure the shader clock the chip holds under this kernel: one s_memtime / s_memrealtime
+// pair around each wave's whole life (nothing inside the walk), printed by launch_prune.  Diagnostic builds only.
+#ifdef CRAB_CLOCK
+__device__ unsigned long long *g_clock_buf;
+#endif
 // Build with -DCRAB_PROF to get a per-phase cycle breakdown of the tree walk (s_memtime, summed per wave, printed by
 // launch_prune to stderr).  Diagnostic builds only: scripts/gpu_prof_phases.sh.
 #ifdef CRAB_PROF
@@ -734,6 +740,9 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #ifdef CRAB_PROF
     unsigned long long prof_keep[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#ifdef CRAB_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = n_work * xcd / N_XCD, chunk_hi = n_work * (xcd + 1) / N_XCD;
     for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
@@ -799,6 +808,15 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             for (int i = 0; i < 12; ++i) g_prof_buf[((size_t)blockIdx.x * 4 + wave) * 12 + i] = prof_keep[i];
 #endif
     }
+#ifdef CRAB_CLOCK
+    if (lane == 0) {
+        unsigned long long *cb = g_clock_buf + ((size_t)blockIdx.x * 4 + wave) * 4;
+        cb[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        cb[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        cb[2] = clk_r0;
+        cb[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);  // XCC_ID, HW_ID
+    }
+#endif
 }
 
 // amdgpu_num_vgpr wants a literal: one entry point per tile width
@@ -882,10 +900,45 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
     }
     (void)hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 12 * 4 * 4096, stream);
 #endif
+#ifdef CRAB_CLOCK
+    static unsigned long long *d_clock = nullptr;
+    if (!d_clock) {
+        (void)hipMalloc((void **)&d_clock, sizeof(unsigned long long) * 4 * 4 * 4096);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clock_buf), &d_clock, sizeof(d_clock));
+    }
+    (void)hipMemsetAsync(d_clock, 0, sizeof(unsigned long long) * 4 * 4 * 4096, stream);
+#endif
     if (nt == 1)
         hipLaunchKernelGGL(prune_kernel_nt1, dim3(grid), dim3(256), lds, stream, a, n_tiles);
     else
         hipLaunchKernelGGL(prune_kernel_nt2, dim3(grid), dim3(256), lds, stream, a, n_tiles);
+#ifdef CRAB_CLOCK
+    {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h((size_t)grid * 4 * 4);
+        (void)hipMemcpy(h.data(), d_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        std::vector<double> ghz, cyc;
+        unsigned long long r_first = ~0ull;
+        for (size_t wv = 0; wv < (size_t)grid * 4; ++wv)
+            if (h[wv * 4 + 1] > 0) {
+                ghz.push_back((double)h[wv * 4] / (double)h[wv * 4 + 1] * 0.1);
+                cyc.push_back((double)h[wv * 4]);
+                if (h[wv * 4 + 2] < r_first) r_first = h[wv * 4 + 2];
+            }
+        if (std::getenv("CRAB_CLOCK_DUMP"))   // per workgroup: start and end (us after the first wave's start), XCC, SE/CU from HW_ID
+            for (int b = 0; b < grid; ++b) {
+                const unsigned long long *r = &h[(size_t)b * 16];
+                const unsigned hw = (unsigned)r[3], xcc = (unsigned)(r[3] >> 32) & 15;
+                fprintf(stderr, "[crab wg] %4d xcc %u se %u cu %2u  start %8.2f end %8.2f us\n", b, xcc, (hw >> 13) & 7, (hw >> 8) & 15,
+                        (double)(r[2] - r_first) * 0.01, (double)(r[2] + r[1] - r_first) * 0.01);
+            }
+        std::sort(ghz.begin(), ghz.end());
+        std::sort(cyc.begin(), cyc.end());
+        if (!ghz.empty())
+            fprintf(stderr, "[crab clock] NT=%d grid=%d: shader clock median %.3f GHz (min %.3f max %.3f); wave life cycles median %.0f max %.0f\n", nt,
+                    grid, ghz[ghz.size() / 2], ghz.front(), ghz.back(), cyc[cyc.size() / 2], cyc.back());
+    }
+#endif
 #ifdef CRAB_PROF
     {
         (void)hipStreamSynchronize(stream);

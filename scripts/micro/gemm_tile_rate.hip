@@ -3,6 +3,7 @@
 // kernel can reach with this core at a given occupancy.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I crabml_amd/csrc scripts/micro/gemm_tile_rate.hip -o /tmp/gtr && /tmp/gtr
 #include "../../crabml_amd/csrc/crab_kernels.hip"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -15,7 +16,7 @@ struct NoRide {
 };
 
 template <int NT, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(double *out, const double *img, int reps)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(double *out, const double *img, int reps, unsigned long long *clk)
 {
     constexpr int X = Plan<2>::T0, Y = Plan<2>::T1;   // the NT = 2 plan has room for either width
     asm volatile("" ::: "v255");
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(do
     t_scale_seq<X>(0.0, std::make_integer_sequence<int, 16 * NT>{});   // whatever was there: finite or not, timing only
     t_const_seq<X>(1, 0, 64, std::make_integer_sequence<int, 16 * NT>{});
     t_scale_seq<X>(seed, std::make_integer_sequence<int, 16 * NT>{});
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
         for (int r = 0; r < reps; r += 2) {   // ping-pong, like the walk
             gemm_tile<NT, X, Y>(lds_a, NoRide{});
@@ -50,6 +52,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(do
             gemm_tile<NT, Y, X>(lds_a, rb);
         }
     }
+    if (lane == 0) {   // shader clock held under this loop: delta s_memtime / delta s_memrealtime x 100 MHz
+        clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = __builtin_amdgcn_s_memtime() - t0;
+        clk[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
     double s = 0.0;
     r_fma_into<X>(s, seed);
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -60,6 +66,8 @@ void run(int blocks_per_cu)
 {
     const int grid = 256 * blocks_per_cu, reps = 400;
     double *out, *img;
+    unsigned long long *clk;
+    (void)hipMalloc(&clk, sizeof(unsigned long long) * grid * 8);
     (void)hipMalloc(&out, sizeof(double) * grid * 256);
     (void)hipMalloc(&img, sizeof(double) * 4096);
     std::vector<double> h(4096, 1.0 / 64);
@@ -71,17 +79,27 @@ void run(int blocks_per_cu)
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps);
+    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps, clk);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps);
+    hipLaunchKernelGGL((k<NT, MODE>), dim3(grid), dim3(256), 65536, 0, out, img, reps, clk);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)grid * 4 * reps * NT * 256 * 512.0;
-    printf("gemm_tile NT=%d mode=%d waves/SIMD=%d: %.3f ms  %.2f TFLOP/s (64-padded)  %.1f cycles/MFMA/SIMD @2.4GHz\n", NT, MODE, blocks_per_cu, ms, flop / ms / 1e9,
-           ms * 1e-3 * 2.4e9 / ((double)reps * NT * 256 * blocks_per_cu));
+    std::vector<unsigned long long> hc((size_t)grid * 8);
+    (void)hipMemcpy(hc.data(), clk, hc.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz, cyc;
+    for (int i = 0; i < grid * 4; ++i) {
+        ghz.push_back(hc[2 * i] / (double)hc[2 * i + 1] * 0.1);
+        cyc.push_back((double)hc[2 * i]);
+    }
+    std::sort(ghz.begin(), ghz.end());
+    std::sort(cyc.begin(), cyc.end());
+    printf("gemm_tile NT=%d mode=%d waves/SIMD=%d: %.3f ms  %.2f TFLOP/s (64-padded)  shader clock %.3f GHz  %.2f shader cycles/MFMA/SIMD\n", NT, MODE,
+           blocks_per_cu, ms, flop / ms / 1e9, ghz[ghz.size() / 2], cyc[cyc.size() / 2] / ((double)reps * NT * 256) / blocks_per_cu * 1.0);
+    (void)hipFree(clk);
     (void)hipFree(out);
     (void)hipFree(img);
 }
