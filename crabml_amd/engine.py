@@ -179,6 +179,65 @@ class Engine:
                                                site.ctypes.data_as(L.dp) if return_sites else None))
         return (lnL.value, site) if return_sites else lnL.value
 
+    # -- evaluations from model parameters (rate matrices built behind the boundary) ----------
+    def _batch(self, x, B=None, inner=None, name="parameter"):
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        if inner is not None:
+            a = np.ascontiguousarray(a.reshape(-1, inner)) if a.ndim == 1 and a.size == inner else a
+            if a.ndim != 2 or a.shape[1] != inner:
+                raise ValueError(f"{name} must have shape (B, {inner}), got {a.shape}")
+        elif a.ndim != 1:
+            raise ValueError(f"{name} must be a scalar or a vector of B values, got shape {a.shape}")
+        if B is not None and a.shape[0] != B:
+            raise ValueError(f"{name} has {a.shape[0]} entries, expected {B}")
+        return a
+
+    def codon_site_classes(self, kappa, omegas, proportions, pi, branch_lengths, no_clamp=False):
+        """lnL of site-class mixtures given (kappa, class omegas, class proportions); scalars/vectors evaluate one
+        parameter vector and return a float, leading batch dimensions evaluate B vectors and return an array."""
+        single = np.ndim(kappa) == 0
+        ka = self._batch(kappa, name="kappa")
+        B = len(ka)
+        om = np.ascontiguousarray(np.asarray(omegas, dtype=np.float64)).reshape(B, -1)
+        K = om.shape[1]
+        pr = self._batch(proportions, B, K, "proportions")
+        bl = self._batch(branch_lengths, B, self.n_nodes, "branch_lengths")
+        pi_, pp = self._pi(pi)
+        out = np.empty(B)
+        self._check(self._lib.crab_eval_codon_site_classes(self._h, B, K, ka.ctypes.data_as(L.dp), om.ctypes.data_as(L.dp),
+                                                           pr.ctypes.data_as(L.dp), pp, bl.ctypes.data_as(L.dp),
+                                                           L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, out.ctypes.data_as(L.dp)))
+        return float(out[0]) if single else out
+
+    def codon_branch(self, kappa, omega_per_node, pi, branch_lengths, no_clamp=False):
+        """Branch model from (kappa, one omega per node); batched like codon_site_classes."""
+        single = np.ndim(kappa) == 0
+        ka = self._batch(kappa, name="kappa")
+        B = len(ka)
+        om = self._batch(omega_per_node, B, self.n_nodes, "omega_per_node")
+        bl = self._batch(branch_lengths, B, self.n_nodes, "branch_lengths")
+        pi_, pp = self._pi(pi)
+        out = np.empty(B)
+        self._check(self._lib.crab_eval_codon_branch(self._h, B, ka.ctypes.data_as(L.dp), om.ctypes.data_as(L.dp), pp,
+                                                     bl.ctypes.data_as(L.dp), L.CRAB_FLAG_NO_CLAMP if no_clamp else 0,
+                                                     out.ctypes.data_as(L.dp)))
+        return float(out[0]) if single else out
+
+    def codon_branch_site(self, kappa, omega0, omega2, p0, p1, pi, branch_lengths, labels):
+        """Branch-site Model A from (kappa, omega0, omega2, p0, p1); batched like codon_site_classes."""
+        single = np.ndim(kappa) == 0
+        ka = self._batch(kappa, name="kappa")
+        B = len(ka)
+        w0, w2, p0_, p1_ = (self._batch(x, B, name=n) for x, n in ((omega0, "omega0"), (omega2, "omega2"), (p0, "p0"), (p1, "p1")))
+        bl = self._batch(branch_lengths, B, self.n_nodes, "branch_lengths")
+        pi_, pp = self._pi(pi)
+        lab, labp = L.u8(labels)
+        out = np.empty(B)
+        self._check(self._lib.crab_eval_codon_branch_site(self._h, B, ka.ctypes.data_as(L.dp), w0.ctypes.data_as(L.dp),
+                                                          w2.ctypes.data_as(L.dp), p0_.ctypes.data_as(L.dp), p1_.ctypes.data_as(L.dp),
+                                                          pp, bl.ctypes.data_as(L.dp), labp, len(lab), 0, out.ctypes.data_as(L.dp)))
+        return float(out[0]) if single else out
+
     # -- measurement ------------------------------------------------------------------------
     def last_timing(self):
         """(device_ms, prune_kernel_ms, host_eigen_ms) of the last evaluation; HIP events on the engine's stream."""
@@ -242,6 +301,37 @@ def spectral_decompose(Q, pi):
     U, lam, Uinv = np.empty((n, n)), np.empty(n), np.empty((n, n))
     L.check(lib.crab_spectral_decompose(n, Qp, pp, U.ctypes.data_as(L.dp), lam.ctypes.data_as(L.dp), Uinv.ctypes.data_as(L.dp)))
     return U, lam, Uinv
+
+
+def build_site_class_q_matrices(kappa, omegas, proportions, pi):
+    """[K, 61, 61] rate matrices exactly as crab_eval_codon_site_classes builds them (host only)."""
+    lib = L.load()
+    om, omp = L.f64(omegas)
+    pr, prp = L.f64(proportions)
+    pi_, pp = L.f64(pi)
+    if len(pr) != len(om) or pi_.shape != (61,):
+        raise ValueError("omegas and proportions must have equal length and pi 61 entries")
+    Q = np.empty((len(om), 61, 61))
+    L.check(lib.crab_build_site_class_q_matrices(len(om), float(kappa), omp, prp, pp, Q.ctypes.data_as(L.dp)))
+    return Q
+
+
+def discretise_omega(kind, a, b, K):
+    """Median-quantile class omegas: kind "beta" (M7/M8/M8a) or "gamma" (M5, shape a, rate b); host only."""
+    lib = L.load()
+    out = np.empty(int(K))
+    L.check(lib.crab_discretise_omega({"beta": 0, "gamma": 1}[kind], float(a), float(b), int(K), out.ctypes.data_as(L.dp)))
+    return out
+
+
+def model_a_quantities(kappa, omega0, omega2, p0, p1, pi):
+    """(site_class_freqs[4], (qfactor_back, qfactor_fore)) as crab_eval_codon_branch_site computes them (host only)."""
+    lib = L.load()
+    pi_, pp = L.f64(pi)
+    fr, qf = np.empty(4), np.empty(2)
+    L.check(lib.crab_model_a_quantities(float(kappa), float(omega0), float(omega2), float(p0), float(p1), pp,
+                                        fr.ctypes.data_as(L.dp), qf.ctypes.data_as(L.dp)))
+    return fr, (float(qf[0]), float(qf[1]))
 
 
 def device_available() -> bool:

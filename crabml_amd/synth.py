@@ -122,6 +122,7 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
             Q, props = np.stack(m.get_Q_matrices()), np.array(m.get_site_classes()[0])
         site_class = rng.choice(len(props), size=n_sites, p=props / props.sum())
         case.Q, case.proportions = Q, props
+        case.class_omegas = np.array([0.3]) if model == "M0" else np.array(m.get_site_classes()[1])
         case.codes = evolve(parent, bl, pi, lambda v, k: (k, Q[k], bl[v]), site_class, n_sites, rng, gap_fraction)
     elif model == "ModelA":
         p0, p1, w0, w2 = 0.5, 0.3, 0.1, 3.0
@@ -150,13 +151,14 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
             return q, Q3[q], bl[v] * (qf if lab else qb)
 
         case.Q3, case.qfactors, case.site_class_freqs, case.branch_labels = Q3, (qb, qf), freqs, labels
-        case.omega0, case.omega2 = w0, w2
+        case.omega0, case.omega2, case.p0, case.p1 = w0, w2, p0, p1
         case.codes = evolve(parent, bl, pi, q_of, site_class, n_sites, rng, gap_fraction)
     elif model == "free-ratio":
         omegas = np.exp(tree_rng.normal(np.log(0.3), 0.5, size=n_nodes - 1))
         bm = models.CodonBranchModel(pi, np.zeros(n_nodes, dtype=int), free_ratio=True, n_nodes=n_nodes)
         Qn = bm.get_Q_matrices(kappa, omegas)
         case.Q_per_node, case.omegas = Qn, omegas
+        case.omega_per_node = np.concatenate([omegas, omegas[:1]])   # the root's matrix is built (from omega 0) and ignored
         case.codes = evolve(parent, bl, pi, lambda v, k: (0, Qn[v], bl[v]), np.zeros(n_sites, dtype=int), n_sites, rng, gap_fraction)
     else:
         raise ValueError(f"unknown model {model}")

@@ -111,6 +111,44 @@ int crab_eval_branch_site(crab_engine *e, const double *Q3, double qfactor_back,
 int crab_eval_branch(crab_engine *e, int n_q, const double *Q, const double *pi, const double *branch_lengths,
                      int n_branch_lengths, unsigned flags, double *lnL, double *site_lnl);
 
+/* ---- evaluations from model parameters: Q construction behind the boundary ---------------------
+ * crabML builds every rate matrix in Python before each FFI call (models/codon.py:166-246 per matrix, called from the
+ * site-class builders :350-376 (M1a), :441-461 (M2a), :518-536 (M3), :607-627 (M7), :709-729 (M8), :810-830 (M8a) ...,
+ * from models/codon_branch.py:129-161 and from optimize/branch_site.py:150-170).  These entry points take the
+ * parameters themselves, B parameter vectors per call (B = 1 for a single evaluation); 61-state alignments only.
+ * All return lnL[b], b in [0, B); pi is shared by the batch; branch_lengths is [B][n_nodes]. */
+
+/* Site-class mixtures M0 ... M9 once their class omegas and proportions are known (the beta / gamma quantile step,
+ * a handful of scalar ppf calls, stays with the caller): Q_k = Q(kappa, omega_k, pi) / sum_k p_k mu_k, then exactly
+ * crab_eval_site_classes_batch.  kappa: [B]; omegas, proportions: [B][K]. */
+int crab_eval_codon_site_classes(crab_engine *e, int B, int K, const double *kappa, const double *omegas,
+                                 const double *proportions, const double *pi, const double *branch_lengths,
+                                 unsigned flags, double *lnL);
+/* Branch (free-ratio / multi-ratio) model: omega_per_node [B][n_nodes] (the root's entry is built and ignored like the
+ * reference's, codon_branch.py:154-161), each matrix normalised on its own; then as crab_eval_branch. */
+int crab_eval_codon_branch(crab_engine *e, int B, const double *kappa, const double *omega_per_node, const double *pi,
+                           const double *branch_lengths, unsigned flags, double *lnL);
+/* Branch-site Model A from (kappa, omega0, omega2, p0, p1), each [B]: class frequencies
+ * (codon_branch_site.py:108-161), Qfactors (:163-231), the three unnormalised matrices
+ * (optimize/branch_site.py:163-165); then as crab_eval_branch_site.  p0 + p1 >= 1 or < 1e-10 is CRAB_ERR_ARG
+ * (the reference raises ValueError). */
+int crab_eval_codon_branch_site(crab_engine *e, int B, const double *kappa, const double *omega0, const double *omega2,
+                                const double *p0, const double *p1, const double *pi, const double *branch_lengths,
+                                const uint8_t *labels, int n_labels, unsigned flags, double *lnL);
+/* The rate matrices crab_eval_codon_site_classes builds for one parameter vector, [K][61][61].  Host only. */
+int crab_build_site_class_q_matrices(int K, double kappa, const double *omegas, const double *proportions,
+                                     const double *pi, double *Q_out);
+
+/* The quantile step of the discrete-distribution models: omegas_out[j] = ppf((2j+1)/(2K)), j in [0, K), of
+ * beta(a, b) (kind 0: M7 / M8 / M8a, models/codon.py:597-604, 694-701, 795-802) or of gamma(shape a, rate b)
+ * (kind 1: M5, :892-899), shape parameters floored at 0.005 like the reference (:570-571, :864-865).  Replaces the
+ * scipy.stats ppf calls (about 1 ms per objective call in the reference).  Host only. */
+int crab_discretise_omega(int kind, double a, double b, int K, double *omegas_out);
+/* Model A's class frequencies [4] and Qfactors {background, foreground} as crab_eval_codon_branch_site computes them
+ * (codon_branch_site.py:108-231).  Host only. */
+int crab_model_a_quantities(double kappa, double omega0, double omega2, double p0, double p1, const double *pi,
+                            double *site_class_freqs, double *qfactors);
+
 /* Timing of the last crab_eval_* on this engine, in milliseconds (HIP events on the engine's
  * stream): whole device section, and the pruning kernel alone.  For bench.py's roofline block. */
 int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kernel_ms, double *host_eigen_ms);

@@ -456,3 +456,78 @@ def test_batched_parameter_vectors_equal_single_evaluations(gpu_engine_cls):
         again = eng.site_classes_batch(Q, pr, case.pi, bl)
     assert np.array_equal(got, want) and np.array_equal(got, again)
     assert len(set(got.tolist())) >= 6        # the perturbations are visible
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluations from model parameters: rate matrices built behind the boundary, batched (8f.1)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SITE_MODEL_CASES)
+def test_site_class_models_from_parameters(gpu_engine_cls, name):
+    """(kappa, omegas, proportions) in, lnL out: against the same engine fed the reference's own Q stack, and
+    against the reference's Python lnL.  The C-built matrices differ from the reference's in the last bit
+    (summation order), so this is a tolerance comparison, not a bit comparison."""
+    c = load_case(name)
+    ka, om, pr, pi, bl = float(c["kappa"]), c["omegas"], c["proportions"], c["pi"], c["branch_lengths"]
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        from_q = eng.site_classes(c["Q"], pr, pi, bl)
+        from_params = eng.codon_site_classes(ka, om, pr, pi, bl)
+        # a batch: the vector itself, a kappa perturbation, a branch-length perturbation
+        B = 3
+        kas = np.array([ka, ka * (1 + 1e-6), ka])
+        bls = np.repeat(bl[None], B, axis=0)
+        bls[2, 0] *= 1.0 + 1e-6
+        batch = eng.codon_site_classes(kas, np.repeat(om[None], B, 0), np.repeat(pr[None], B, 0), pi, bls)
+        singles = [eng.codon_site_classes(kas[b], om, pr, pi, bls[b]) for b in range(B)]
+    tol = TOTAL_ATOL if name in WELL_CONDITIONED else 1e-5
+    assert abs(from_params - from_q) < 1e-9 * max(1.0, abs(from_q)) if name in WELL_CONDITIONED else abs(from_params - from_q) < tol
+    assert abs(from_params - float(c["lnL_pyref"])) < tol
+    assert batch[0] == from_params
+    assert list(batch) == singles                              # bit-identical to one call per vector
+    assert batch[1] != batch[0] and batch[2] != batch[0]       # the perturbations were seen
+
+
+def test_branch_site_model_a_from_parameters(gpu_engine_cls):
+    c = load_case("lysozymeLarge_modelA")
+    pars = [float(c[k]) for k in ("kappa", "omega0", "omega2", "p0", "p1")]
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        from_q = eng.branch_site(c["Q"], float(c["qfactors"][0]), float(c["qfactors"][1]), float(c["omega0"]), float(c["omega2"]),
+                                 c["site_class_freqs"], c["pi"], c["branch_lengths"], c["branch_labels"])
+        from_params = eng.codon_branch_site(*pars, c["pi"], c["branch_lengths"], c["branch_labels"])
+        # batch of 4: base, omega2 -> 1 (the null model: classes 2a/2b on the foreground use Q(1)), p0 and t perturbed
+        B = 4
+        P = np.repeat(np.array(pars)[None], B, axis=0)
+        P[1, 2] = 1.0
+        P[2, 3] *= 1.0 + 1e-6
+        bls = np.repeat(c["branch_lengths"][None], B, axis=0)
+        bls[3, 1] *= 1.0 + 1e-6
+        batch = eng.codon_branch_site(P[:, 0], P[:, 1], P[:, 2], P[:, 3], P[:, 4], c["pi"], bls, c["branch_labels"])
+        singles = [eng.codon_branch_site(*P[b], c["pi"], bls[b], c["branch_labels"]) for b in range(B)]
+        with pytest.raises(ValueError, match="must be < 1"):
+            eng.codon_branch_site(2.0, 0.1, 2.0, 0.7, 0.4, c["pi"], c["branch_lengths"], c["branch_labels"])
+        with pytest.raises(ValueError, match="Branch labels length"):
+            eng.codon_branch_site(*pars, c["pi"], c["branch_lengths"], c["branch_labels"][:-1])
+    assert abs(from_params - from_q) < 1e-9
+    assert abs(from_params - float(c["lnL_paml"])) < 1e-5      # tests/test_branch_site_likelihood.py:121-128
+    assert batch[0] == from_params
+    assert list(batch) == singles
+    assert len(set(batch.tolist())) == B
+    assert batch[1] < batch[0]                                 # the null model cannot beat the alternative at its optimum
+
+
+def test_branch_model_from_parameters(gpu_engine_cls):
+    from crabml_amd import synth
+    case = synth.make_case("free-ratio", 40, 800, seed=23)
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        from_q = eng.branch(case.Q_per_node, case.pi, case.branch_lengths)
+        from_params = eng.codon_branch(case.kappa, case.omega_per_node, case.pi, case.branch_lengths)
+        B = 3
+        om = np.repeat(case.omega_per_node[None], B, axis=0)
+        om[1, 5] *= 1.0 + 1e-6
+        om[2, :] = 0.3                                         # one shared omega: the M0 model
+        batch = eng.codon_branch(np.full(B, case.kappa), om, case.pi, np.repeat(case.branch_lengths[None], B, 0))
+        singles = [eng.codon_branch(case.kappa, om[b], case.pi, case.branch_lengths) for b in range(B)]
+        m0 = eng.codon_site_classes(case.kappa, [0.3], [1.0], case.pi, case.branch_lengths)
+    assert abs(from_params - from_q) < 1e-9 * abs(from_q)
+    assert batch[0] == from_params
+    assert list(batch) == singles
+    assert batch[2] == m0                                      # tests/test_branch_models.py:131-174, exactly

@@ -330,3 +330,78 @@ def test_spectral_decomposition_of_every_fixture_matrix():
         for Q in c["Q"]:
             U, lam, Ui = spectral_decompose(Q, c["pi"])
             assert np.abs((U * lam) @ Ui - Q).max() <= 1e-13 * np.abs(Q).max(), name
+
+
+# ---------------------------------------------------------------------------------------------
+# Q construction behind the boundary: the host side of crab_eval_codon_*
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [f"lysozyme_{m}" for m in LYSOZYME_MODELS] + ["hiv_m8a", "lysin_m2a_gaps", "synthetic_edge"])
+def test_site_class_rate_matrices_built_in_c_match_the_reference_fixtures(name):
+    """The fixtures hold the Q stacks the reference's Python model classes produced (tests/golden/make_golden.py)
+    next to the (kappa, omegas, proportions, pi) they were built from."""
+    from crabml_amd.engine import build_site_class_q_matrices
+    c = load_case(name)
+    Q = build_site_class_q_matrices(float(c["kappa"]), c["omegas"], c["proportions"], c["pi"])
+    assert Q.shape == c["Q"].shape
+    scale = np.abs(c["Q"]).max()
+    assert np.abs(Q - c["Q"]).max() <= 4e-15 * scale      # summation order only (the reference's 3.7e-16 story, codon.py:14-19)
+    # rows sum to zero, the mixture's mean rate is one
+    assert np.abs(Q.sum(axis=2)).max() < 1e-13
+    rate = sum(p * -(c["pi"] * np.diagonal(q)).sum() for p, q in zip(c["proportions"], Q))
+    assert abs(rate - 1.0) < 1e-13
+
+
+def test_model_a_quantities_built_in_c_match_the_reference_fixture():
+    from crabml_amd.engine import model_a_quantities
+    c = load_case("lysozymeLarge_modelA")
+    fr, qf = model_a_quantities(c["kappa"], c["omega0"], c["omega2"], c["p0"], c["p1"], c["pi"])
+    np.testing.assert_allclose(fr, c["site_class_freqs"], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(qf, c["qfactors"], rtol=1e-14, atol=0)
+    with pytest.raises(ValueError, match="must be < 1"):          # codon_branch_site.py:139-142
+        model_a_quantities(2.0, 0.1, 2.0, 0.7, 0.3, c["pi"])
+    with pytest.raises(ValueError, match="too small"):            # :143-146
+        model_a_quantities(2.0, 0.1, 2.0, 0.0, 0.0, c["pi"])
+    with pytest.raises(ValueError, match="kappa"):
+        model_a_quantities(-1.0, 0.1, 2.0, 0.5, 0.3, c["pi"])
+    from crabml_amd.engine import build_site_class_q_matrices
+    with pytest.raises(ValueError, match="omega"):
+        build_site_class_q_matrices(2.0, [0.1, np.nan], [0.5, 0.5], c["pi"])
+
+
+@pytest.mark.parametrize("name", ["lysozyme_m5", "lysozyme_m7", "lysozyme_m8", "lysozyme_m8a", "hiv_m8a"])
+def test_quantile_discretisation_in_c_matches_the_reference_fixtures(name):
+    """The fixtures' class omegas came out of the reference's scipy ppf calls (models/codon.py:597-604, 694-701,
+    795-802, 892-899) for the parameters in params_json; lysozyme_m7 / m8a sit at the 0.005 floor of the shape
+    parameters, where quantiles run from 1e-263 to 1 - 1e-16."""
+    import json
+    from crabml_amd.engine import discretise_omega
+    c = load_case(name)
+    par = json.loads(str(c["params_json"]))
+    K = par["ncatG"]
+    got = discretise_omega("gamma", par["alpha"], par["beta"], K) if name.endswith("m5") else discretise_omega("beta", par["p_beta"], par["q_beta"], K)
+    ref = c["omegas"][:K]
+    # omega enters Q as omega * pi_j next to entries of order pi_j: what has to agree is omega on the scale of one
+    assert np.abs(got - ref).max() <= 1e-13
+    big = ref > 1e-200
+    assert np.abs(got[big] / ref[big] - 1.0).max() <= 2e-11   # and relatively wherever omega is not a denormal-scale zero
+
+
+def test_quantile_functions_against_scipy_over_the_optimisers_range():
+    from scipy.stats import beta, gamma
+    from crabml_amd.engine import discretise_omega
+    worst = 0.0
+    for a in (0.005, 0.05, 0.5, 0.7, 1.0, 1.5, 2.0, 9.5, 30.0, 99.0):
+        for b in (0.005, 0.2, 0.5, 1.0, 1.5, 5.0, 13.5, 30.0, 99.0):
+            for K in (1, 4, 10):
+                p = (2.0 * np.arange(K) + 1.0) / (2.0 * K)
+                for kind, ref in (("beta", beta.ppf(p, a, b)), ("gamma", gamma.ppf(p, a, scale=1.0 / b))):
+                    got = discretise_omega(kind, a, b, K)
+                    assert np.all(np.diff(got) >= 0) and np.all(got >= 0)
+                    ok = ref > 1e-290
+                    worst = max(worst, np.abs(got[ok] / ref[ok] - 1.0).max() if ok.any() else 0.0)
+                    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, ref.max())
+    assert worst <= 5e-11
+    # the reference's floors (models/codon.py:570-571, 864-865)
+    assert np.array_equal(discretise_omega("beta", 1e-9, -3.0, 5), discretise_omega("beta", 0.005, 0.005, 5))
+    with pytest.raises(ValueError):
+        discretise_omega("beta", np.nan, 1.0, 5)
