@@ -107,37 +107,120 @@ double now_ms()
 
 uint64_t hash_words(const void *p, size_t bytes, uint64_t seed);
 
-// Host cache of spectral decompositions, keyed by the contents of (Q, pi).  Finite-difference gradients perturb one
-// parameter at a time, and a branch-length perturbation changes no rate matrix at all, so most of the K (site classes)
-// or n_nodes (free-ratio) decompositions of a call repeat those of the call before (lib.rs:163-169,387-393 redo all).
-struct EigCache {
+// Device-resident pool of spectral decompositions.  Finite-difference gradients perturb one parameter at a time, and a
+// branch-length perturbation changes no rate matrix at all, so most of the K (site classes) or n_nodes (free-ratio)
+// decompositions of a call repeat those of the call before (lib.rs:163-169,387-393 redo all of them).  An entry is
+// keyed either by the contents of (Q, pi) or -- for the entry points that take model parameters -- by (kappa, omega, pi)
+// and then holds the decomposition of the *unnormalised* matrix: every normalisation the models apply is a scalar that
+// folds into the branch length (exp((Q / mu) t) = exp(Q (t / mu))), so a change of class proportions touches no
+// eigensystem.  Hits cost neither a host copy nor an upload: kernel 1 reads the pool through slot indices.
+struct EigPool {
     struct Entry {
-        std::vector<double> Q, pi, eig;
+        bool used = false, by_params = false;
+        uint64_t h = 0, stamp = 0;
+        double kappa = 0, omega = 0;
+        std::vector<double> Q, pi;   // Q only for content keys
     };
-    std::unordered_map<uint64_t, std::vector<Entry>> map;
-    size_t count = 0;
-    static constexpr size_t MAX_ENTRIES = 4096;  // x 95 KB = 390 MB at most, then the cache starts over
-    const double *find(uint64_t h, const double *Q, const double *pi, int n) const
+    static constexpr size_t SOFT_MAX = 4096;  // x 66 KB = 270 MB of HBM; least recently used entries make room beyond it
+    std::vector<Entry> slots;
+    std::unordered_multimap<uint64_t, int> index;
+    std::vector<int> free_list;
+    double *d = nullptr;
+    size_t cap = 0;
+    uint64_t clock = 0;
+
+    int find_content(uint64_t h, const double *Q, const double *pi, int n)
     {
-        auto it = map.find(h);
-        if (it == map.end()) return nullptr;
-        for (const Entry &en : it->second)
-            if (std::memcmp(en.Q.data(), Q, sizeof(double) * n * n) == 0 && std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0)
-                return en.eig.data();
-        return nullptr;
-    }
-    void insert(uint64_t h, const double *Q, const double *pi, int n, const double *eig)
-    {
-        if (count >= MAX_ENTRIES) {
-            map.clear();
-            count = 0;
+        auto r = index.equal_range(h);
+        for (auto it = r.first; it != r.second; ++it) {
+            Entry &en = slots[it->second];
+            if (!en.by_params && std::memcmp(en.Q.data(), Q, sizeof(double) * n * n) == 0 && std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0) {
+                en.stamp = clock;
+                return it->second;
+            }
         }
-        Entry en;
-        en.Q.assign(Q, Q + (size_t)n * n);
-        en.pi.assign(pi, pi + n);
-        en.eig.assign(eig, eig + crab::EIG_STRIDE);
-        map[h].push_back(std::move(en));
-        ++count;
+        return -1;
+    }
+    int find_params(uint64_t h, double kappa, double omega, const double *pi, int n)
+    {
+        auto r = index.equal_range(h);
+        for (auto it = r.first; it != r.second; ++it) {
+            Entry &en = slots[it->second];
+            if (en.by_params && std::memcmp(&en.kappa, &kappa, 8) == 0 && std::memcmp(&en.omega, &omega, 8) == 0 &&
+                std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0) {
+                en.stamp = clock;
+                return it->second;
+            }
+        }
+        return -1;
+    }
+    void drop(int slot)
+    {
+        Entry &en = slots[slot];
+        auto r = index.equal_range(en.h);
+        for (auto it = r.first; it != r.second; ++it)
+            if (it->second == slot) {
+                index.erase(it);
+                break;
+            }
+        en = Entry{};
+    }
+    // n slots for this call's new decompositions: free ones first, then growth up to SOFT_MAX, then the least recently
+    // used entries that this call does not use itself, then growth again
+    void allocate(int n, std::vector<int> &out, hipStream_t stream)
+    {
+        out.clear();
+        while ((int)out.size() < n && !free_list.empty()) {
+            out.push_back(free_list.back());
+            free_list.pop_back();
+        }
+        int need = n - (int)out.size();
+        if (need > 0 && cap >= SOFT_MAX) {
+            std::vector<std::pair<uint64_t, int>> old;
+            for (size_t i = 0; i < cap; ++i)
+                if (slots[i].used && slots[i].stamp != clock) old.emplace_back(slots[i].stamp, (int)i);
+            std::sort(old.begin(), old.end());
+            for (size_t i = 0; i < old.size() && need > 0; ++i, --need) {
+                drop(old[i].second);
+                out.push_back(old[i].second);
+            }
+        }
+        if (need > 0) {
+            const size_t want = std::max<size_t>({cap + need, std::min<size_t>(2 * cap, SOFT_MAX), 32});
+            double *nd = nullptr;
+            HIP_CHECK(hipMalloc((void **)&nd, want * crab::EIG_STRIDE * sizeof(double)));
+            if (d) {
+                hipError_t err = hipMemcpyAsync(nd, d, cap * crab::EIG_STRIDE * sizeof(double), hipMemcpyDeviceToDevice, stream);
+                if (err == hipSuccess) err = hipStreamSynchronize(stream);
+                if (err != hipSuccess) {
+                    (void)hipFree(nd);
+                    throw HipError{std::string("growing the eigensystem pool: ") + hipGetErrorString(err)};
+                }
+                (void)hipFree(d);
+            }
+            d = nd;
+            slots.resize(want);
+            for (size_t i = want; i-- > cap;) free_list.push_back((int)i);   // lowest index handed out first
+            cap = want;
+            while ((int)out.size() < n) {
+                out.push_back(free_list.back());
+                free_list.pop_back();
+            }
+        }
+    }
+    void give_back(const std::vector<int> &got)
+    {
+        for (int sl : got)
+            if (!slots[sl].used) free_list.push_back(sl);
+    }
+    void release()
+    {
+        if (d) (void)hipFree(d);
+        d = nullptr;
+        cap = 0;
+        slots.clear();
+        index.clear();
+        free_list.clear();
     }
 };
 
@@ -172,12 +255,12 @@ struct crab_engine : TreeProgram {
     // ---- device state ----
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
-    DevBuf<double> d_weights, d_eig, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
+    DevBuf<double> d_weights, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
     DevBuf<int32_t> d_eig_id, d_stack_e, d_e;
     PinBuf<double> h_eig, h_small, h_out;
     PinBuf<int32_t> h_int;
 
-    EigCache eig_cache;
+    EigPool eig_pool;
     int64_t eig_hits = 0, eig_misses = 0;
 
     // ---- last-eval facts ----
@@ -189,7 +272,8 @@ struct crab_engine : TreeProgram {
     ~crab_engine()
     {
         (void)hipSetDevice(device);
-        d_ops.release(); d_codes.release(); d_weights.release(); d_eig.release(); d_teff.release(); d_P.release();
+        eig_pool.release();
+        d_ops.release(); d_codes.release(); d_weights.release(); d_teff.release(); d_P.release();
         d_pi.release(); d_props.release(); d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
         d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_stack_e.release(); d_e.release();
         h_eig.release(); h_small.release(); h_out.release(); h_int.release();
@@ -593,7 +677,8 @@ void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t 
 // ---------------------------------------------------------------------------------------------
 struct EvalPlan {
     int n_eig = 0;                      // eigensystems to decompose
-    const double *Q = nullptr;          // [n_eig][n][n]
+    const double *Q = nullptr;          // [n_eig][n][n], or
+    std::vector<std::pair<double, double>> kw;  // [n_eig] distinct (kappa, omega): unnormalised codon matrices, built on a miss
     int M = 0;                          // transition matrices to build
     std::vector<int32_t> eig_id;        // [M]
     std::vector<double> t_eff;          // [M]
@@ -620,15 +705,25 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     const int n = e->n_states;
     HIP_CHECK(hipSetDevice(e->device));
 
-    // ---- host: eigensystems.  Identical rate matrices are decomposed once (within the call and across calls),
-    // the rest in parallel, one task per matrix (replaces the serial loop at lib.rs:163-169) ----
+    // ---- host: eigensystems.  Identical rate matrices are decomposed once (within the call and across calls: the pool
+    // lives on the device), the rest in parallel, one task per matrix (replaces the serial loop at lib.rs:163-169) ----
     const double t0 = now_ms();
     const double *Q = pl.Q;
+    const bool by_params = !pl.kw.empty();
+    EigPool &pool = e->eig_pool;
+    ++pool.clock;
     std::vector<int32_t> uniq_of(pl.n_eig);       // rate matrix -> slot among this call's distinct eigensystems
     std::vector<int> uniq_src;                    // slot -> first rate matrix showing it
     std::vector<uint64_t> qhash(pl.n_eig);
-    {
-        const uint64_t pih = hash_words(pi, sizeof(double) * n, 11);
+    const uint64_t pih = hash_words(pi, sizeof(double) * n, 11);
+    if (by_params) {                              // the caller lists distinct (kappa, omega) pairs
+        for (int i = 0; i < pl.n_eig; ++i) {
+            const double kw[2] = {pl.kw[i].first, pl.kw[i].second};
+            qhash[i] = hash_words(kw, sizeof(kw), pih ^ 0x9e3779b97f4a7c15ull);
+            uniq_of[i] = i;
+            uniq_src.push_back(i);
+        }
+    } else {
         parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
         std::unordered_map<uint64_t, std::vector<int>> seen;
         for (int i = 0; i < pl.n_eig; ++i) {
@@ -649,26 +744,52 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     }
     const int n_uniq = (int)uniq_src.size();
-    e->h_eig.ensure((size_t)n_uniq * EIG_STRIDE);
-    double *h_eig = e->h_eig.p;
+    std::vector<int32_t> pool_slot(n_uniq, -1);
     std::vector<int> todo;
     for (int u = 0; u < n_uniq; ++u) {
         const int i = uniq_src[u];
-        if (const double *hit = e->eig_cache.find(qhash[i], Q + (size_t)i * n * n, pi, n))
-            std::memcpy(h_eig + (size_t)u * EIG_STRIDE, hit, sizeof(double) * EIG_STRIDE);
-        else
-            todo.push_back(u);
+        pool_slot[u] = by_params ? pool.find_params(qhash[i], pl.kw[i].first, pl.kw[i].second, pi, n)
+                                 : pool.find_content(qhash[i], Q + (size_t)i * n * n, pi, n);
+        if (pool_slot[u] < 0) todo.push_back(u);
     }
     e->eig_hits += n_uniq - (int)todo.size();
     e->eig_misses += (int)todo.size();
+    e->h_eig.ensure(todo.size() * EIG_STRIDE);
+    double *h_eig = e->h_eig.p;
     std::vector<char> ok(todo.size(), 1);
+    std::vector<double> Qbuilt(by_params ? todo.size() * (size_t)n * n : 0);
     parallel_for((int)todo.size(), [&](int j) {
-        const int u = todo[j];
-        ok[j] = spectral_decompose(n, Q + (size_t)uniq_src[u] * n * n, pi, h_eig + (size_t)u * EIG_STRIDE) ? 1 : 0;
+        const int i = uniq_src[todo[j]];
+        const double *Qi = Q + (size_t)i * n * n;
+        if (by_params) {
+            double *dst = Qbuilt.data() + (size_t)j * n * n;
+            crab_build_codon_q_matrix(pl.kw[i].first, pl.kw[i].second, pi, 1, 1.0, dst);
+            Qi = dst;
+        }
+        ok[j] = spectral_decompose(n, Qi, pi, h_eig + (size_t)j * EIG_STRIDE) ? 1 : 0;
     });
     for (size_t j = 0; j < todo.size(); ++j)
         if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(uniq_src[todo[j]]));
-    // (the new decompositions enter the cache further down, while the device is busy)
+    std::vector<int> new_slots;
+    struct SlotGuard {   // slots taken but not registered (an error further down) go back to the free list
+        EigPool &pool;
+        std::vector<int> &got;
+        ~SlotGuard() { pool.give_back(got); }
+    } slot_guard{pool, new_slots};
+    if (!todo.empty()) {
+        pool.allocate((int)todo.size(), new_slots, e->stream);
+        // consecutive slots travel in one copy (a first call fills a fresh pool front to back)
+        for (size_t j = 0; j < todo.size();) {
+            size_t r = j + 1;
+            while (r < todo.size() && new_slots[r] == new_slots[r - 1] + 1) ++r;
+            const hipError_t err = hipMemcpyAsync(pool.d + (size_t)new_slots[j] * EIG_STRIDE, h_eig + j * EIG_STRIDE,
+                                                  (r - j) * EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice, e->stream);
+            if (err != hipSuccess) throw HipError{std::string("uploading eigensystems: ") + hipGetErrorString(err)};
+            j = r;
+        }
+        for (size_t j = 0; j < todo.size(); ++j) pool_slot[todo[j]] = new_slots[j];
+    }
+    // (the new entries are registered further down, while the device is busy)
     e->last_eigen_ms = now_ms() - t0;
 
     // ---- uploads ----
@@ -691,9 +812,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
     const size_t n_int = (size_t)pl.M;
     e->h_int.ensure(n_int);
-    for (int m = 0; m < pl.M; ++m) e->h_int.p[m] = uniq_of[pl.eig_id[m]];
+    for (int m = 0; m < pl.M; ++m) e->h_int.p[m] = pool_slot[uniq_of[pl.eig_id[m]]];
 
-    e->d_eig.ensure((size_t)n_uniq * EIG_STRIDE);
     e->d_teff.ensure(pl.M);
     e->d_pi.ensure(NS);
     e->d_props.ensure(pl.K);
@@ -711,7 +831,6 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_lnL.ensure(G);
     if (pl.by_class) e->d_byclass.ensure((size_t)e->n_pat * pl.K + 1);
 
-    HIP_CHECK(hipMemcpyAsync(e->d_eig.p, h_eig, (size_t)n_uniq * EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_teff.p, hs, pl.M * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_pi.p, hs + pl.M, NS * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_props.p, hs + pl.M + NS, pl.K * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -719,7 +838,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
-    launch_build_p(e->d_eig.p, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, e->stream);
+    launch_build_p(pool.d, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, e->stream);
 
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
@@ -774,9 +893,21 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     HIP_CHECK(hipEventRecord(e->ev_end, e->stream));
     // host work that can hide behind the device: remember the decompositions made for this call
-    for (int u : todo) {
-        const int i = uniq_src[u];
-        e->eig_cache.insert(qhash[i], Q + (size_t)i * n * n, pi, n, h_eig + (size_t)u * EIG_STRIDE);
+    for (size_t j = 0; j < todo.size(); ++j) {
+        const int i = uniq_src[todo[j]];
+        EigPool::Entry &en = pool.slots[new_slots[j]];
+        en.used = true;
+        en.by_params = by_params;
+        en.h = qhash[i];
+        en.stamp = pool.clock;
+        en.pi.assign(pi, pi + n);
+        if (by_params) {
+            en.kappa = pl.kw[i].first;
+            en.omega = pl.kw[i].second;
+        } else {
+            en.Q.assign(Q + (size_t)i * n * n, Q + (size_t)(i + 1) * n * n);
+        }
+        pool.index.emplace(en.h, new_slots[j]);
     }
     HIP_CHECK(hipStreamSynchronize(e->stream));
     HIP_CHECK(hipGetLastError());
@@ -829,6 +960,77 @@ void plan_site_classes(crab_engine *e, EvalPlan &pl, int K, const double *Q, con
             pl.t_eff[m] = v == e->root ? 0.0 : t[v];
             pl.pidx[m] = m;
         }
+}
+
+}  // namespace
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// the codon graph: ordered single-nucleotide neighbour pairs among the 61 sense codons in PAML order
+// (codon.rs:63-87,167-220), row by row with ascending column
+// ---------------------------------------------------------------------------------------------
+struct CodonGraph {
+    int row_begin[62];
+    int col[526];
+    bool ts[526], nonsyn[526];
+    double rate(int k, double kappa, double omega) const
+    {
+        double r = 1.0;
+        if (ts[k]) r *= kappa;
+        if (nonsyn[k]) r *= omega;
+        return r;
+    }
+};
+
+const CodonGraph &codon_graph()
+{
+    static const CodonGraph g = [] {
+        CodonGraph g{};
+        static const char aa[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+        int sense[61], rank[64], m = 0;
+        for (int c = 0; c < 64; ++c) {
+            rank[c] = -1;
+            if (aa[c] != '*') {
+                sense[m] = c;
+                rank[c] = m++;
+            }
+        }
+        int n = 0;
+        for (int i = 0; i < 61; ++i) {
+            g.row_begin[i] = n;
+            for (int j = 0; j < 61; ++j) {
+                const int x = sense[i] ^ sense[j];
+                int pos = -1;
+                if (x != 0 && (x & ~0x03) == 0) pos = 2;
+                else if (x != 0 && (x & ~0x0c) == 0) pos = 1;
+                else if (x != 0 && (x & ~0x30) == 0) pos = 0;
+                if (pos < 0) continue;
+                const int sh = 2 * (2 - pos), ni = (sense[i] >> sh) & 3, nj = (sense[j] >> sh) & 3;
+                g.col[n] = j;
+                g.ts[n] = (ni ^ nj) == 1;                     // T<->C (0,1) and A<->G (2,3)
+                g.nonsyn[n] = aa[sense[i]] != aa[sense[j]];
+                ++n;
+            }
+        }
+        g.row_begin[61] = n;
+        return g;
+    }();
+    return g;
+}
+
+// mu(kappa, omega) = -sum_i pi_i Q_ii of the unnormalised matrix, with the sums taken in the order
+// crab_build_codon_q_matrix takes them (same bits as building the matrix and reading its diagonal)
+double codon_mean_rate(double kappa, double omega, const double *pi)
+{
+    const CodonGraph &g = codon_graph();
+    double er = 0.0;
+    for (int i = 0; i < 61; ++i) {
+        double rs = 0.0;
+        for (int k = g.row_begin[i]; k < g.row_begin[i + 1]; ++k) rs += g.rate(k, kappa, omega) * pi[g.col[k]];
+        er += pi[i] * -rs;
+    }
+    return -er;
 }
 
 }  // namespace
@@ -1165,35 +1367,15 @@ int crab_matrix_exponential(int device, int n, const double *Q, const double *pi
 int crab_build_codon_q_matrix(double kappa, double omega, const double *pi, int has_factor, double factor, double *Q)
 {
     if (!pi || !Q) return CRAB_ERR_ARG;
-    static const char aa[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
-    int sense[61], rank[64], m = 0;
-    for (int c = 0; c < 64; ++c) {
-        rank[c] = -1;
-        if (aa[c] != '*') {
-            sense[m] = c;
-            rank[c] = m++;
-        }
-    }
+    const CodonGraph &g = codon_graph();
     std::fill(Q, Q + 61 * 61, 0.0);
     for (int i = 0; i < 61; ++i) {
-        const int ci = sense[i];
-        for (int pos = 0; pos < 3; ++pos) {
-            const int sh = 2 * (2 - pos), ni = (ci >> sh) & 3;
-            for (int nj = 0; nj < 4; ++nj) {
-                if (nj == ni) continue;
-                const int cj = (ci & ~(3 << sh)) | (nj << sh);
-                const int j = rank[cj];
-                if (j < 0) continue;
-                double rate = 1.0;
-                if ((ni ^ nj) == 1) rate *= kappa;  // T<->C (0,1) and A<->G (2,3)
-                if (aa[ci] != aa[cj]) rate *= omega;
-                Q[i * 61 + j] = rate * pi[j];
-            }
-        }
-    }
-    for (int i = 0; i < 61; ++i) {
         double rs = 0.0;
-        for (int j = 0; j < 61; ++j) rs += Q[i * 61 + j];
+        for (int k = g.row_begin[i]; k < g.row_begin[i + 1]; ++k) {
+            const double q = g.rate(k, kappa, omega) * pi[g.col[k]];
+            Q[i * 61 + g.col[k]] = q;
+            rs += q;
+        }
         Q[i * 61 + i] = -rs;
     }
     double div = factor;
@@ -1274,11 +1456,8 @@ void model_a_quantities(double kappa, double omega0, double omega2, double p0, d
     freqs[3] = p2 * p1 / t01;
     const double w_back = (p0 / t01) * omega0 + (p1 / t01) * 1.0;
     const double w_fore = p0 * omega0 + p1 * 1.0 + p2 * omega2;
-    std::vector<double> Q(61 * 61);
-    crab_build_codon_q_matrix(kappa, w_back, pi, 1, 1.0, Q.data());
-    qfactors[0] = 1.0 / mean_rate61(Q.data(), pi);
-    crab_build_codon_q_matrix(kappa, w_fore, pi, 1, 1.0, Q.data());
-    qfactors[1] = 1.0 / mean_rate61(Q.data(), pi);
+    qfactors[0] = 1.0 / codon_mean_rate(kappa, w_back, pi);
+    qfactors[1] = 1.0 / codon_mean_rate(kappa, w_fore, pi);
 }
 
 }  // namespace
@@ -1333,12 +1512,36 @@ int crab_eval_codon_site_classes(crab_engine *e, int B, int K, const double *kap
             fail(CRAB_ERR_ARG, "crab_eval_codon_site_classes: bad arguments");
         if (e->n_states != 61) fail(CRAB_ERR_ARG, "codon-model entry points need a 61-state alignment");
         for (int b = 0; b < B; ++b) check_params("crab_eval_codon_site_classes", kappa[b], omegas + (size_t)b * K, K);
-        std::vector<double> Q((size_t)B * K * 61 * 61);
-        parallel_for(B, [&](int b) {
-            build_site_class_qs(K, kappa[b], omegas + (size_t)b * K, proportions + (size_t)b * K, pi, Q.data() + (size_t)b * K * 61 * 61);
-        });
-        const int rc = crab_eval_site_classes_batch(e, B, K, Q.data(), proportions, pi, branch_lengths, flags, lnL);
-        if (rc != CRAB_OK) fail(rc, e->err);
+        // distinct unnormalised matrices Q(kappa_b, omega_bk); the mixture's shared scale sum_k p_k mu_k
+        // (e.g. models/codon.py:709-729) divides the branch lengths instead of the matrices
+        const int nn = e->n_nodes;
+        QPool qp;
+        EvalPlan pl;
+        pl.n_groups = B;
+        pl.K = B * K;
+        pl.M = B * K * nn;
+        pl.eig_id.resize(pl.M);
+        pl.t_eff.resize(pl.M);
+        pl.pidx.resize((size_t)pl.K * nn);
+        for (int b = 0; b < B; ++b) {
+            double scale = 0.0;
+            for (int k = 0; k < K; ++k) scale += proportions[(size_t)b * K + k] * codon_mean_rate(kappa[b], omegas[(size_t)b * K + k], pi);
+            if (!(scale > 0.0)) fail(CRAB_ERR_ARG, "site-class rate matrices have zero mean rate");
+            for (int k = 0; k < K; ++k) {
+                const int q = qp.get(kappa[b], omegas[(size_t)b * K + k]);
+                for (int v = 0; v < nn; ++v) {
+                    const int m = (b * K + k) * nn + v;
+                    pl.eig_id[m] = q;
+                    pl.t_eff[m] = v == e->root ? 0.0 : branch_lengths[(size_t)b * nn + v] / scale;
+                    pl.pidx[m] = m;
+                }
+            }
+        }
+        pl.kw = qp.keys;
+        pl.n_eig = (int)qp.keys.size();
+        pl.props.assign(proportions, proportions + (size_t)B * K);
+        pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
+        run_plan(e, pl, pi, lnL, nullptr, nullptr);
     });
 }
 
@@ -1352,7 +1555,7 @@ int crab_eval_codon_branch(crab_engine *e, int B, const double *kappa, const dou
         if (e->n_states != 61) fail(CRAB_ERR_ARG, "codon-model entry points need a 61-state alignment");
         const int nn = e->n_nodes;
         for (int b = 0; b < B; ++b) check_params("crab_eval_codon_branch", kappa[b], omega_per_node + (size_t)b * nn, nn);
-        // one individually normalised matrix per distinct (kappa, omega) (codon_branch.py:154-161), one class per vector
+        // one eigensystem per distinct (kappa, omega) (codon_branch.py:154-161), one class per vector
         QPool pool;
         EvalPlan pl;
         pl.n_groups = B;
@@ -1368,10 +1571,14 @@ int crab_eval_codon_branch(crab_engine *e, int B, const double *kappa, const dou
                 pl.t_eff[m] = v == e->root ? 0.0 : branch_lengths[(size_t)b * nn + v];
                 pl.pidx[m] = m;
             }
+        pl.kw = pool.keys;
         pl.n_eig = (int)pool.keys.size();
-        std::vector<double> Q((size_t)pl.n_eig * 61 * 61);
-        parallel_for(pl.n_eig, [&](int i) { crab_build_codon_q_matrix(pool.keys[i].first, pool.keys[i].second, pi, 0, 0.0, Q.data() + (size_t)i * 61 * 61); });
-        pl.Q = Q.data();
+        std::vector<double> mu(pl.n_eig);   // each matrix is normalised on its own: t / mu
+        parallel_for(pl.n_eig, [&](int i) { mu[i] = codon_mean_rate(pool.keys[i].first, pool.keys[i].second, pi); });
+        for (int m = 0; m < pl.M; ++m) {
+            if (!(mu[pl.eig_id[m]] > 0.0)) fail(CRAB_ERR_ARG, "rate matrix with zero mean rate");
+            pl.t_eff[m] /= mu[pl.eig_id[m]];
+        }
         pl.props.assign(B, 1.0);
         pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
         run_plan(e, pl, pi, lnL, nullptr, nullptr);
@@ -1431,11 +1638,8 @@ int crab_eval_codon_branch_site(crab_engine *e, int B, const double *kappa, cons
                 }
             }
         }
+        pl.kw = pool.keys;   // unnormalised (optimize/branch_site.py:163-165)
         pl.n_eig = (int)pool.keys.size();
-        std::vector<double> Q((size_t)pl.n_eig * 61 * 61);
-        for (int i = 0; i < pl.n_eig; ++i)   // unnormalised (optimize/branch_site.py:163-165)
-            crab_build_codon_q_matrix(pool.keys[i].first, pool.keys[i].second, pi, 1, 1.0, Q.data() + (size_t)i * 61 * 61);
-        pl.Q = Q.data();
         run_plan(e, pl, pi, lnL, nullptr, nullptr);
     });
 }

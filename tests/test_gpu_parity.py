@@ -531,3 +531,36 @@ def test_branch_model_from_parameters(gpu_engine_cls):
     assert batch[0] == from_params
     assert list(batch) == singles
     assert batch[2] == m0                                      # tests/test_branch_models.py:131-174, exactly
+
+
+def test_eigensystem_pool_growth_and_eviction(gpu_engine_cls):
+    """The device-resident pool of decompositions grows (contents must survive the move) and, past 4096 entries,
+    recycles its least recently used slots: results must not depend on what the pool has seen before."""
+    c = load_case("lysozyme_m3")
+    pi, bl = c["pi"], c["branch_lengths"]
+    rng = np.random.default_rng(5)
+
+    def fresh(ka, om, pr):
+        with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as e2:
+            return e2.codon_site_classes(ka, om, pr, pi, bl)
+
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        first = eng.codon_site_classes(2.0, [0.1, 0.9, 2.0], [0.5, 0.3, 0.2], pi, bl)           # 3 entries, pool of 32
+        K = 60
+        om = np.sort(rng.uniform(0.01, 3.0, K))
+        pr = np.full(K, 1.0 / K)
+        grown = eng.codon_site_classes(2.0, np.concatenate([[0.1, 0.9, 2.0], om]), np.concatenate([[0.2, 0.2, 0.2], 0.4 * pr]), pi, bl)
+        assert eng.codon_site_classes(2.0, [0.1, 0.9, 2.0], [0.5, 0.3, 0.2], pi, bl) == first    # hits, after the pool moved
+        # content-keyed entries share the pool
+        q_lnL = eng.site_classes(c["Q"], c["proportions"], pi, bl)
+        # push more than 4096 distinct matrices through, 64 per call
+        for i in range(66):
+            eng.codon_site_classes(2.0 + 0.01 * (i + 1), np.linspace(0.05, 2.5, 64), np.full(64, 1.0 / 64), pi, bl)
+        again = eng.codon_site_classes(2.0, [0.1, 0.9, 2.0], [0.5, 0.3, 0.2], pi, bl)            # evicted by now: decomposed anew
+        q_again = eng.site_classes(c["Q"], c["proportions"], pi, bl)
+        last = eng.codon_site_classes(2.66, np.linspace(0.05, 2.5, 64), np.full(64, 1.0 / 64), pi, bl)   # still resident
+    assert first == fresh(2.0, [0.1, 0.9, 2.0], [0.5, 0.3, 0.2])
+    assert grown == fresh(2.0, np.concatenate([[0.1, 0.9, 2.0], om]), np.concatenate([[0.2, 0.2, 0.2], 0.4 * pr]))
+    assert again == first and q_again == q_lnL
+    assert last == fresh(2.66, np.linspace(0.05, 2.5, 64), np.full(64, 1.0 / 64))
+    assert abs(q_lnL - float(c["lnL_pyref"])) < TOTAL_ATOL
