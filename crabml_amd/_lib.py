@@ -36,6 +36,7 @@ SIGNATURES = {
     "crab_eval_site_classes": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, C.c_uint, dp, dp]),
     "crab_eval_site_classes_batch": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, dp, dp, C.c_uint, dp]),
     "crab_eval_site_lnl_by_class": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_uint, dp]),
+    "crab_eval_beb_grid": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, C.c_int, ip, dp, C.c_uint, dp, dp, dp]),
     "crab_eval_branch_site": (C.c_int, [vp, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, bp, C.c_int,
                                         C.c_uint, dp, dp]),
     "crab_eval_branch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, C.c_uint, dp, dp]),

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <list>
@@ -256,7 +257,8 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_eig_id, d_stack_e, d_e;
+    DevBuf<int32_t> d_eig_id, d_stack_e, d_e, d_beb_cols;
+    DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
     PinBuf<double> h_eig, h_small, h_out;
     PinBuf<int32_t> h_int;
 
@@ -276,6 +278,7 @@ struct crab_engine : TreeProgram {
         d_ops.release(); d_codes.release(); d_weights.release(); d_teff.release(); d_P.release();
         d_pi.release(); d_props.release(); d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
         d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_stack_e.release(); d_e.release();
+        d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
         h_eig.release(); h_small.release(); h_out.release(); h_int.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
@@ -689,6 +692,15 @@ struct EvalPlan {
     int mix_mode = MIX_LOGSUMEXP_CLAMP;
     bool by_class = false;
     bool clamp = true;
+    struct Beb {                        // grid integration of site posteriors after the pruning pass (kernel 4)
+        int G = 0, n_mix = 0;
+        const int32_t *cols = nullptr;  // [G][n_mix] class index of each mixture component
+        const double *props = nullptr;  // [G][n_mix]
+        double *post = nullptr;         // out [n_sites][n_mix]
+        double *lnfx = nullptr;         // out [G] or null
+        double *ln_fx = nullptr;        // out: ln f(X) = logsumexp_g lnfx[g]
+    };
+    const Beb *beb = nullptr;
 };
 
 void check_ready(crab_engine *e)
@@ -864,8 +876,55 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     launch_prune(pa, grid, e->stream);
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
-    e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0));
-    if (pl.by_class) {
+    e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0) +
+                    (pl.beb ? (size_t)2 * pl.beb->G + (size_t)e->n_pat * pl.beb->n_mix : 0));
+    if (pl.beb) {
+        const EvalPlan::Beb &bb = *pl.beb;
+        const size_t gm = (size_t)bb.G * bb.n_mix;
+        e->d_beb_F.ensure((size_t)pl.K * e->n_pat_pad);
+        e->d_beb_cols.ensure(gm);
+        e->d_beb_props.ensure(gm);
+        e->d_beb_lnfx.ensure(bb.G);
+        e->d_beb_w.ensure(bb.G);
+        e->d_beb_post.ensure((size_t)std::max<int64_t>(1, e->n_pat) * bb.n_mix);
+        // (the grid tables are caller memory, borrowed until this call returns)
+        HIP_CHECK(hipMemcpyAsync(e->d_beb_cols.p, bb.cols, gm * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_CHECK(hipMemcpyAsync(e->d_beb_props.p, bb.props, gm * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        BebArgs ba{};
+        ba.f = e->d_f.p;
+        ba.e = e->d_e.p;
+        ba.K = pl.K;
+        ba.n_pat = e->n_pat;
+        ba.n_pat_pad = e->n_pat_pad;
+        ba.weights = e->d_weights.p;
+        ba.F = e->d_beb_F.p;
+        ba.G = bb.G;
+        ba.n_mix = bb.n_mix;
+        ba.cols = e->d_beb_cols.p;
+        ba.props = e->d_beb_props.p;
+        ba.lnfx = e->d_beb_lnfx.p;
+        ba.grid_w = e->d_beb_w.p;
+        ba.post = e->d_beb_post.p;
+        double *h_lnfx = e->h_out.p + G, *h_w = h_lnfx + bb.G, *h_post = h_w + bb.G;
+        launch_beb_scale(ba, e->stream);
+        launch_beb_grid_lnf(ba, e->stream);
+        HIP_CHECK(hipMemcpyAsync(h_lnfx, e->d_beb_lnfx.p, bb.G * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (e->n_pat == 0)
+            for (int g = 0; g < bb.G; ++g) h_lnfx[g] = 0.0;
+        // ln f(X) = ln sum_g exp(lnfX_g) around the largest term (beb.py:609-611); posterior grid weights
+        double s2 = -std::numeric_limits<double>::infinity(), sum = 0.0;
+        for (int g = 0; g < bb.G; ++g) s2 = std::max(s2, h_lnfx[g]);
+        for (int g = 0; g < bb.G; ++g) sum += std::exp(h_lnfx[g] - s2);
+        const double ln_fx = std::log(sum) + s2;
+        for (int g = 0; g < bb.G; ++g) h_w[g] = std::exp(h_lnfx[g] - ln_fx);
+        HIP_CHECK(hipMemcpyAsync(e->d_beb_w.p, h_w, bb.G * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        launch_beb_posteriors(ba, e->stream);
+        if (e->n_pat > 0)
+            HIP_CHECK(hipMemcpyAsync(h_post, e->d_beb_post.p, (size_t)e->n_pat * bb.n_mix * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (bb.lnfx) std::copy(h_lnfx, h_lnfx + bb.G, bb.lnfx);
+        if (bb.ln_fx) *bb.ln_fx = ln_fx;
+    } else if (pl.by_class) {
         launch_by_class(e->d_f.p, e->d_e.p, pl.K, e->n_pat, e->n_pat_pad, pl.clamp ? 1 : 0, e->d_byclass.p, e->stream);
         HIP_CHECK(hipMemcpyAsync(e->h_out.p + G, e->d_byclass.p, (size_t)e->n_pat * pl.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     } else {
@@ -922,7 +981,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
     e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
 
-    if (pl.by_class) {
+    if (pl.beb) {
+        const double *src = e->h_out.p + G + 2 * (size_t)pl.beb->G;
+        const int nm = pl.beb->n_mix;
+        for (int64_t s = 0; s < e->n_sites; ++s) {
+            const int64_t p = e->site_to_pat[s];
+            if (p < e->pat_begin || p >= e->pat_end) continue;
+            std::memcpy(pl.beb->post + (size_t)s * nm, src + (size_t)(p - e->pat_begin) * nm, nm * sizeof(double));
+        }
+    } else if (pl.by_class) {
         const double *src = e->h_out.p + G;
         for (int64_t s = 0; s < e->n_sites; ++s) {
             const int64_t p = e->site_to_pat[s];
@@ -1165,6 +1232,36 @@ int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const do
         pl.by_class = true;
         pl.clamp = !(flags & CRAB_FLAG_NO_CLAMP);
         run_plan(e, pl, pi, nullptr, nullptr, out);
+    });
+}
+
+int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi, const double *branch_lengths, int G, int n_mix,
+                       const int32_t *cols, const double *props, unsigned flags, double *posteriors, double *lnfx, double *ln_fx)
+{
+    (void)flags;
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (K < 1 || !Q || !pi || !branch_lengths || G < 1 || !cols || !props || !posteriors)
+            fail(CRAB_ERR_ARG, "crab_eval_beb_grid: bad arguments");
+        if (K > NS - 1) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: at most 63 classes");
+        if (n_mix < 1 || n_mix > BEB_MAX_MIX) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: n_mix must be in [1, 16]");
+        for (size_t i = 0; i < (size_t)G * n_mix; ++i)
+            if (cols[i] < 0 || cols[i] >= K) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: class index out of range in the grid table");
+        if (e->pat_begin != 0 || e->pat_end != e->n_pat_total)
+            fail(CRAB_ERR_STATE, "crab_eval_beb_grid needs the whole alignment on one engine: f(X | grid point) is a product over all sites");
+        EvalPlan pl;
+        plan_site_classes(e, pl, K, Q, branch_lengths);
+        EvalPlan::Beb bb;
+        bb.G = G;
+        bb.n_mix = n_mix;
+        bb.cols = cols;
+        bb.props = props;
+        bb.post = posteriors;
+        bb.lnfx = lnfx;
+        bb.ln_fx = ln_fx;
+        pl.beb = &bb;
+        run_plan(e, pl, pi, nullptr, nullptr, nullptr);
     });
 }
 

@@ -147,4 +147,28 @@ void launch_mix(const MixArgs &a, hipStream_t stream);
 void launch_by_class(const double *f, const int32_t *e, int K, int64_t n_pat, int64_t n_pat_pad, int clamp, double *out,
                      hipStream_t stream);
 
+// ---- kernel 4: grid integration of Bayes empirical Bayes site posteriors (analysis/beb.py:575-661) ----
+// The K per-class site likelihoods are computed once; every grid point g is a mixture of n_mix of them,
+// sum_c props[g][c] * F[cols[g][c]][p].  Stage 1 scales each pattern's K likelihoods by their maximum (beb.py:581-585),
+// stage 2 gives ln f(X | g) per grid point (:589-607), the host turns those into posterior grid weights
+// exp(lnfX_g - ln f(X)) (:609-612), stage 3 accumulates each pattern's class posteriors over the grid (:614-659).
+constexpr int BEB_MAX_MIX = 16;
+struct BebArgs {
+    const double *f;          // [K][n_pat_pad] scaled likelihoods from the pruning kernel
+    const int32_t *e;         //               and their exponents
+    int32_t K;
+    int64_t n_pat, n_pat_pad;
+    const double *weights;    // [n_pat_pad] pattern multiplicities
+    double *F;                // [K][n_pat_pad] work: likelihoods relative to the pattern's best class
+    int32_t G, n_mix;
+    const int32_t *cols;      // [G][n_mix]
+    const double *props;      // [G][n_mix]
+    double *lnfx;             // [G] out of stage 2
+    const double *grid_w;     // [G] in to stage 3
+    double *post;             // [n_pat][n_mix] out of stage 3
+};
+void launch_beb_scale(const BebArgs &a, hipStream_t stream);
+void launch_beb_grid_lnf(const BebArgs &a, hipStream_t stream);
+void launch_beb_posteriors(const BebArgs &a, hipStream_t stream);
+
 }  // namespace crab

@@ -1080,4 +1080,112 @@ void launch_by_class(const double *f, const int32_t *e, int K, int64_t n_pat, in
                        (long long)n_pat_pad, clamp, out);
 }
 
+// =============================================================================================
+// kernel 4: Bayes empirical Bayes grid integration (analysis/beb.py:575-661)
+// =============================================================================================
+// stage 1: F[k][p] = exp(x_k - max_k x_k), x_k = ln max(f_k, 1e-300) as compute_site_log_likelihoods_by_class
+// returns it (likelihood.rs:328-335; beb.py:581-585)
+__global__ __launch_bounds__(256) void beb_scale_kernel(BebArgs a)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_pat) return;
+    double mx = -__builtin_inf();
+    for (int k = 0; k < a.K; ++k) {
+        const size_t o = (size_t)k * a.n_pat_pad + p;
+        const double x = ln_site(a.f[o], a.e[o], true);
+        mx = x > mx ? x : mx;
+    }
+    for (int k = 0; k < a.K; ++k) {
+        const size_t o = (size_t)k * a.n_pat_pad + p;
+        a.F[o] = exp(ln_site(a.f[o], a.e[o], true) - mx);
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;  // valid on lane 0
+}
+
+// stage 2: one wavefront per grid point; lanes stride the patterns (coalesced rows of F), fixed-order reduction.
+// lnfX_g = sum_p w_p ln f_p(g), a pattern entering only if f_p(g) > 1e-300 (beb.py:604-607)
+__global__ __launch_bounds__(256) void beb_grid_lnf_kernel(BebArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= a.G) return;
+    const double *col[BEB_MAX_MIX];
+    double pr[BEB_MAX_MIX];
+#pragma unroll
+    for (int c = 0; c < BEB_MAX_MIX; ++c) {   // fixed trip count: the tables stay in registers
+        const bool on = c < a.n_mix;
+        col[c] = a.F + (size_t)(on ? a.cols[(size_t)g * a.n_mix + c] : 0) * a.n_pat_pad;
+        pr[c] = on ? a.props[(size_t)g * a.n_mix + c] : 0.0;
+    }
+    double acc = 0.0;
+    for (long long p = lane; p < a.n_pat; p += 64) {
+        double fh = 0.0;
+#pragma unroll
+        for (int c = 0; c < BEB_MAX_MIX; ++c)
+            if (c < a.n_mix) fh += pr[c] * col[c][p];
+        if (fh > 1e-300) acc += a.weights[p] * log(fh);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.lnfx[g] = acc;
+}
+
+// stage 3: one wavefront per pattern; lanes stride the grid.  post[p][c] = sum_g (pr_c F_c / f_p(g)) grid_w[g]
+// with the reference's guards (f_p(g) < 1e-300 and class terms < 1e-300 are skipped, beb.py:634-647)
+__global__ __launch_bounds__(256) void beb_posterior_kernel(BebArgs a)
+{
+    __shared__ double Fs[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p = (long long)blockIdx.x * 4 + wave;
+    if (p >= a.n_pat) return;
+    if (lane < a.K) Fs[wave][lane] = a.F[(size_t)lane * a.n_pat_pad + p];   // K <= 63: one likelihood per lane
+    __builtin_amdgcn_wave_barrier();
+    double acc[BEB_MAX_MIX];
+#pragma unroll
+    for (int c = 0; c < BEB_MAX_MIX; ++c) acc[c] = 0.0;
+    for (int g = lane; g < a.G; g += 64) {
+        double term[BEB_MAX_MIX], fh = 0.0;
+#pragma unroll
+        for (int c = 0; c < BEB_MAX_MIX; ++c) {
+            term[c] = 0.0;
+            if (c < a.n_mix) {
+                term[c] = a.props[(size_t)g * a.n_mix + c] * Fs[wave][a.cols[(size_t)g * a.n_mix + c]];
+                fh += term[c];
+            }
+        }
+        if (fh < 1e-300) continue;
+        const double w = a.grid_w[g];
+#pragma unroll
+        for (int c = 0; c < BEB_MAX_MIX; ++c)
+            if (c < a.n_mix && !(term[c] < 1e-300)) acc[c] += term[c] / fh * w;
+    }
+#pragma unroll
+    for (int c = 0; c < BEB_MAX_MIX; ++c)
+        if (c < a.n_mix) {
+            const double s = wave_sum(acc[c]);
+            if (lane == 0) a.post[(size_t)p * a.n_mix + c] = s;
+        }
+}
+
+void launch_beb_scale(const BebArgs &a, hipStream_t stream)
+{
+    if (a.n_pat <= 0) return;
+    hipLaunchKernelGGL(beb_scale_kernel, dim3((unsigned)((a.n_pat + 255) / 256)), dim3(256), 0, stream, a);
+}
+void launch_beb_grid_lnf(const BebArgs &a, hipStream_t stream)
+{
+    if (a.G <= 0) return;
+    hipLaunchKernelGGL(beb_grid_lnf_kernel, dim3((unsigned)((a.G + 3) / 4)), dim3(256), 0, stream, a);
+}
+void launch_beb_posteriors(const BebArgs &a, hipStream_t stream)
+{
+    if (a.n_pat <= 0) return;
+    hipLaunchKernelGGL(beb_posterior_kernel, dim3((unsigned)((a.n_pat + 3) / 4)), dim3(256), 0, stream, a);
+}
+
 }  // namespace crab

@@ -150,6 +150,26 @@ class Engine:
                                                           L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, out.ctypes.data_as(L.dp)))
         return out
 
+    def beb_grid(self, Q, pi, branch_lengths, cols, props):
+        """Site posteriors integrated over a parameter grid (analysis/beb.py:575-661 on the device).
+        Q: [K, n, n]; cols int [G, n_mix] and props [G, n_mix] describe each grid point's mixture.
+        Returns (posteriors [n_sites, n_mix], lnfX per grid point [G], ln f(X))."""
+        Q_, Qp = self._q_stack(Q)
+        pi_, pp = self._pi(pi)
+        bl, blp = self._bl(branch_lengths)
+        cols_ = np.ascontiguousarray(cols, dtype=np.int32)
+        props_ = np.ascontiguousarray(props, dtype=np.float64)
+        if cols_.ndim != 2 or props_.shape != cols_.shape:
+            raise ValueError("cols and props must both have shape (G, n_mix)")
+        G, n_mix = cols_.shape
+        post = np.full((self.n_sites, n_mix), np.nan)
+        lnfx = np.empty(G)
+        ln_fx = C.c_double()
+        self._check(self._lib.crab_eval_beb_grid(self._h, Q_.shape[0], Qp, pp, blp, G, n_mix, cols_.ctypes.data_as(L.ip),
+                                                 props_.ctypes.data_as(L.dp), 0, post.ctypes.data_as(L.dp),
+                                                 lnfx.ctypes.data_as(L.dp), C.byref(ln_fx)))
+        return post, lnfx, ln_fx.value
+
     def branch_site(self, Q3, qfactor_back, qfactor_fore, omega0, omega2, site_class_freqs, pi, branch_lengths, labels,
                     return_sites=False):
         Q_, Qp = self._q_stack(Q3)

@@ -98,6 +98,17 @@ int crab_eval_site_classes_batch(crab_engine *e, int B, int K, const double *Q, 
 int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const double *pi,
                                 const double *branch_lengths, unsigned flags, double *out);
 
+/* Bayes empirical Bayes site posteriors on PAML's fixed grid: everything BEBCalculator.compute_site_posteriors_paml
+ * (analysis/beb.py:513-661) does after building its rate matrices -- the K-class site likelihood table
+ * (compute_site_log_likelihoods_by_class, beb.py:577 -> lib.rs:214-258), its per-site scaling (:581-585), ln f(X | g) for
+ * every grid point (:589-607), ln f(X) (:609-611) and the class posteriors of every site (:614-659; in the reference
+ * pure-Python loops over n_sites x 10 000 grid points, twice).  Grid point g mixes n_mix (<= 16) of the K classes:
+ * f_s(g) = sum_c props[g*n_mix + c] * f_{cols[g*n_mix + c], s}.  posteriors: [n_sites][n_mix]; lnfx: optional [G];
+ * ln_fx: optional scalar.  Needs the whole alignment on this engine (no pattern slice). */
+int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi, const double *branch_lengths, int G,
+                       int n_mix, const int32_t *cols, const double *props, unsigned flags, double *posteriors,
+                       double *lnfx, double *ln_fx);
+
 /* compute_branch_site_log_likelihood (lib.rs:287-345 -> branch_site_likelihood.rs:115-299).
  * Q3: [3][n][n] = Q(omega0), Q(1), Q(omega2), unnormalised; labels[n_labels], n_labels must be
  * n_nodes-1, indexed by node id, values 0/1.  lnL = sum_s ln sum_k freqs[k] f_{k,s}; no clamp. */

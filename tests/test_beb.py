@@ -1,0 +1,69 @@
+"""BEB grid integration: the CPU restatement against the reference's own output, and the host mirror
+of the reference's grid / rate-matrix construction.  CPU only; the device path is in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from util import load_case
+
+PAML_SITES = [15, 17, 37, 41, 50, 62, 114, 126]                      # tests/data/paml_reference/lysozyme_m2a_out.txt:256-263
+PAML_PR_W_GT_1 = [0.693, 0.695, 0.744, 0.920, 0.835, 0.578, 0.689, 0.577]
+
+
+@pytest.fixture(scope="module")
+def beb_case():
+    return load_case("lysozyme_m2a_beb")
+
+
+def test_grid_and_rate_matrices_match_the_reference(beb_case):
+    from crabml_amd import beb
+    c = beb_case
+    cols, props = beb.paml_grid_m2a()
+    assert cols.shape == props.shape == (10000, 3)
+    w = np.array(beb.paml_omega_grid())
+    np.testing.assert_array_equal(props[:, 0], c["grid_p0"])
+    np.testing.assert_array_equal(props[:, 1], c["grid_p1"])
+    np.testing.assert_array_equal(w[cols[:, 0]], c["grid_omega0"])
+    np.testing.assert_array_equal(w[cols[:, 2]], c["grid_omega2"])
+    assert np.all(cols[:, 1] == 10) and np.all(w[cols[:, 1]] == 1.0)
+    np.testing.assert_allclose(props.sum(axis=1), 1.0, atol=1e-15)
+    Q = beb.beb_rate_matrices(float(c["kappa"]), c["pi"], c["mle_proportions"], c["mle_omegas"])
+    assert np.abs(Q - c["Q"]).max() <= 4e-15 * np.abs(c["Q"]).max()
+
+
+def test_oracle_reproduces_the_reference_posteriors_and_pamls_table(beb_case):
+    from crabml_amd import beb
+    from oracle import beb as obeb
+    c = beb_case
+    cols, props = beb.paml_grid_m2a()
+    post, lnfx, ln_fx = obeb.site_posteriors(c["site_log_liks"], cols, props)
+    ref = c["posteriors_ref"]
+    assert np.abs(post - ref).max() <= 1e-13
+    big = ref > 1e-8
+    assert np.abs(post[big] / ref[big] - 1.0).max() <= 1e-10
+    np.testing.assert_allclose(post.sum(axis=1), 1.0, atol=1e-12)
+    assert np.isfinite(ln_fx) and ln_fx >= lnfx.max()
+    # PAML's own output, to its three printed decimals
+    got = post[np.array(PAML_SITES) - 1, 2]
+    assert np.abs(got - PAML_PR_W_GT_1).max() < 5e-4
+
+
+def test_oracle_loop_form_equals_vectorised_form(beb_case):
+    """The literal restatement (running maximum, guards, loop order of beb.py:587-661) on a reduced problem."""
+    from crabml_amd import beb
+    from oracle import beb as obeb
+    c = beb_case
+    cols, props = beb.paml_grid_m2a()
+    pick = np.arange(0, 10000, 97)
+    lnf = c["site_log_liks"][:9].copy()
+    lnf[3, :] = np.log(1e-300)          # an all-underflowed column: equal classes after scaling
+    lnf[4, 11:] = np.log(1e-300)        # classes that drop below the 1e-300 guard after scaling
+    a = obeb.site_posteriors_loops(lnf, cols[pick], props[pick])
+    b = obeb.site_posteriors(lnf, cols[pick], props[pick])
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-13)
+    assert abs(a[2] - b[2]) < 1e-11
+    # weights = multiplicities: a table of unique patterns gives the same grid likelihoods as the site table
+    dup = np.concatenate([lnf, lnf[:4]])
+    wts = np.array([2, 2, 2, 2, 1, 1, 1, 1, 1], dtype=float)
+    np.testing.assert_allclose(obeb.site_posteriors(dup, cols[pick], props[pick])[1],
+                               obeb.site_posteriors(lnf, cols[pick], props[pick], weights=wts)[1], rtol=1e-13)

@@ -564,3 +564,62 @@ def test_eigensystem_pool_growth_and_eviction(gpu_engine_cls):
     assert again == first and q_again == q_lnL
     assert last == fresh(2.66, np.linspace(0.05, 2.5, 64), np.full(64, 1.0 / 64))
     assert abs(q_lnL - float(c["lnL_pyref"])) < TOTAL_ATOL
+
+
+# ---------------------------------------------------------------------------------------------
+# BEB site posteriors integrated over PAML's grid on the device (analysis/beb.py:513-661)
+# ---------------------------------------------------------------------------------------------
+def test_beb_grid_integration_against_the_reference_and_paml(gpu_engine_cls):
+    from crabml_amd import beb
+    from oracle import beb as obeb
+    c = load_case("lysozyme_m2a_beb")
+    cols, props = beb.paml_grid_m2a()
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        post, lnfx, ln_fx = eng.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props)
+        table = eng.site_lnl_by_class(c["Q"], c["pi"], c["branch_lengths"])
+        post2, ln_fx2 = beb.m2a_site_posteriors(eng, float(c["kappa"]), c["pi"], c["mle_proportions"], c["mle_omegas"], c["branch_lengths"])
+        again = eng.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props)
+        with pytest.raises(ValueError, match="class index out of range"):
+            eng.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols + 19, props)
+        with pytest.raises(ValueError, match="n_mix"):
+            eng.beb_grid(c["Q"], c["pi"], c["branch_lengths"], np.zeros((4, 17), dtype=np.int32), np.ones((4, 17)))
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"], pattern_begin=0, pattern_end=64) as part:
+        with pytest.raises(ValueError, match="whole alignment"):
+            part.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props)
+    ref = c["posteriors_ref"]                                  # the reference's compute_site_posteriors_paml
+    big = ref > 1e-8
+    assert np.abs(post - ref).max() <= 1e-11
+    assert np.abs(post[big] / ref[big] - 1.0).max() <= 1e-9    # its input table came from the CPU oracle, ours from the device
+    # against the oracle fed the device's own [S, 21] table: the integration alone, strict
+    o_post, o_lnfx, o_ln_fx = obeb.site_posteriors(table, cols, props)
+    assert np.abs(post[big] / o_post[big] - 1.0).max() <= SITE_RTOL
+    assert np.abs(post - o_post).max() <= 1e-14
+    np.testing.assert_allclose(lnfx, o_lnfx, rtol=1e-12)
+    assert abs(ln_fx - o_ln_fx) < TOTAL_ATOL
+    # PAML's printed Pr(w>1) (tests/data/paml_reference/lysozyme_m2a_out.txt:256-263)
+    got = post[np.array([15, 17, 37, 41, 50, 62, 114, 126]) - 1, 2]
+    assert np.abs(got - [0.693, 0.695, 0.744, 0.920, 0.835, 0.578, 0.689, 0.577]).max() < 5e-4
+    np.testing.assert_allclose(post.sum(axis=1), 1.0, atol=1e-12)
+    assert np.abs(post2 - post).max() <= 1e-12 and abs(ln_fx2 - ln_fx) < 1e-9   # host-built matrices differ in the last bit
+    assert np.array_equal(again[0], post) and again[2] == ln_fx                 # fixed-order reductions: bit-identical repeats
+
+
+def test_beb_grid_integration_at_size(gpu_engine_cls):
+    """2 000 codons x 30 taxa under M2a: the device against the vectorised oracle on the device's own class table
+    (the reference's loops would need 2 x 2e7 Python iterations here)."""
+    from crabml_amd import beb, models, synth
+    from oracle import beb as obeb
+    case = synth.make_case("M8", 30, 2000, seed=31)
+    m = models.M2aCodonModel(kappa=2.5, omega0=0.2, omega2=2.5, p0=0.7, p1=0.2, pi=case.pi)
+    pr, om = m.get_site_classes()
+    Q = beb.beb_rate_matrices(2.5, case.pi, pr, om)
+    cols, props = beb.paml_grid_m2a()
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        post, lnfx, ln_fx = eng.beb_grid(Q, case.pi, case.branch_lengths, cols, props)
+        table = eng.site_lnl_by_class(Q, case.pi, case.branch_lengths)
+    o_post, o_lnfx, o_ln_fx = obeb.site_posteriors(table, cols, props)
+    big = o_post > 1e-8
+    assert np.abs(post[big] / o_post[big] - 1.0).max() <= SITE_RTOL
+    assert np.abs(post - o_post).max() <= 1e-13
+    np.testing.assert_allclose(lnfx, o_lnfx, rtol=1e-12)
+    assert abs(ln_fx - o_ln_fx) < TOTAL_ATOL * 10      # a sum of 2 000 terms of magnitude ~30: 1e-12 relative
