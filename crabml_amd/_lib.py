@@ -53,6 +53,7 @@ SIGNATURES = {
     "crab_build_codon_q_matrix": (C.c_int, [C.c_double, C.c_double, dp, C.c_int, C.c_double, dp]),
     "crab_compile_tree": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compress_patterns": (C.c_int, [ip, C.c_int, C.c_int64, C.c_int, lp, dp, lp, lp]),
+    "crab_host_pool_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crab_spectral_decompose": (C.c_int, [C.c_int, dp, dp, dp, dp, dp]),
     "crab_compute_log_likelihood": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_int, ip, ip, dp, ip, C.c_int, C.c_int64, ip, dp]),
     "crab_compute_site_class_log_likelihood": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int, ip, ip, dp, ip,

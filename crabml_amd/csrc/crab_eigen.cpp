@@ -207,7 +207,15 @@ bool spectral_decompose(int n, const double *Q, const double *pi, double *out)
 // worker pool
 // ---------------------------------------------------------------------------------------------
 namespace {
+// Several engines (one host thread each, e.g. crabml_amd.dist.map_genes) may call parallel_for at once: every call is a
+// job in a shared list; pool threads take indices from the oldest job that still has some, and the caller works on its
+// own job too, so a job never waits for a thread that is busy elsewhere.
 class Pool {
+    struct Job {   // lives on its caller's stack; every field is guarded by m_
+        const std::function<void(int)> *fn;
+        int n, next = 0, done = 0;
+    };
+
   public:
     Pool()
     {
@@ -238,54 +246,49 @@ class Pool {
             for (int i = 0; i < n; ++i) fn(i);
             return;
         }
-        std::lock_guard<std::mutex> serial(run_m_);  // one parallel_for at a time
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0);
-            pending_ = n;
-            ++epoch_;
-        }
-        cv_.notify_all();
-        work();
+        Job job;
+        job.fn = &fn;
+        job.n = n;
         std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        jobs_.push_back(&job);
+        cv_.notify_all();
+        drain(&job, lk);
+        done_cv_.wait(lk, [&] { return job.done == job.n; });
     }
 
   private:
-    void work()
+    // Run indices of `job` until none is left to hand out.  lk is held on entry and on return.  A job is alive as long
+    // as one of its indices has not finished, so it is only touched under the lock, and not again after the increment
+    // that completes it.
+    void drain(Job *job, std::unique_lock<std::mutex> &lk)
     {
-        for (;;) {
-            const int i = next_.fetch_add(1);
-            if (i >= n_) break;
-            (*fn_)(i);
-            std::lock_guard<std::mutex> lk(m_);
-            if (--pending_ == 0) done_cv_.notify_all();
+        while (job->next < job->n) {
+            const int i = job->next++;
+            if (job->next == job->n) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));   // nothing left to hand out
+            const std::function<void(int)> *fn = job->fn;
+            lk.unlock();
+            (*fn)(i);
+            lk.lock();
+            if (++job->done == job->n) {
+                done_cv_.notify_all();
+                return;
+            }
         }
     }
     void loop()
     {
-        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-                if (stop_) return;
-                seen = epoch_;
-                if (!fn_) continue;
-            }
-            work();
+            cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+            if (stop_) return;
+            drain(jobs_.front(), lk);
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex m_, run_m_;
+    std::vector<Job *> jobs_;
+    std::mutex m_;
     std::condition_variable cv_, done_cv_;
-    const std::function<void(int)> *fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, pending_ = 0, n_threads_ = 1;
-    unsigned long epoch_ = 0;
+    int n_threads_ = 1;
     bool stop_ = false;
 };
 

@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <limits>
 #include <cstdio>
@@ -1411,6 +1413,33 @@ int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, 
         if (site_to_pattern) std::copy(s2p.begin(), s2p.end(), site_to_pattern);
         if (pattern_weight) std::copy(cnt.begin(), cnt.end(), pattern_weight);
         if (first_site) std::copy(first.begin(), first.end(), first_site);
+    });
+}
+
+// Exercises the host worker pool the way concurrent engines do: `callers` threads issue `rounds` parallel loops of `n`
+// indices each at the same time; every index of every loop must run exactly once.  Returns CRAB_OK or CRAB_ERR_STATE.
+int crab_host_pool_selftest(int callers, int n, int rounds)
+{
+    return guarded(nullptr, [&] {
+        if (callers < 1 || n < 1 || rounds < 1) fail(CRAB_ERR_ARG, "crab_host_pool_selftest: bad arguments");
+        std::atomic<int> bad{0};
+        std::vector<std::thread> th;
+        for (int c = 0; c < callers; ++c)
+            th.emplace_back([&, c] {
+                std::vector<int> hits(n);
+                for (int r = 0; r < rounds; ++r) {
+                    std::fill(hits.begin(), hits.end(), 0);
+                    volatile double sink = 0.0;
+                    parallel_for(n, [&](int i) {
+                        for (int k = 0; k < 200 * ((i + c + r) % 7); ++k) sink = sink + k;   // uneven work
+                        ++hits[i];   // each index belongs to exactly one thread
+                    });
+                    for (int i = 0; i < n; ++i)
+                        if (hits[i] != 1) ++bad;
+                }
+            });
+        for (auto &t : th) t.join();
+        if (bad.load() != 0) fail(CRAB_ERR_STATE, "host pool ran an index " + std::to_string(bad.load()) + " times too many or too few");
     });
 }
 

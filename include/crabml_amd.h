@@ -194,6 +194,10 @@ int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, 
 /* CachedQMatrix::new (matrix.rs:31-75) as the engine does it on the host: U, lam, U^-1 (n x n, n, n x n). */
 int crab_spectral_decompose(int n, const double *Q, const double *pi, double *U, double *lam, double *Uinv);
 
+/* Host worker pool under concurrent callers (several engines, one host thread each): `callers` threads run `rounds`
+ * parallel loops of n indices at once and check that every index ran exactly once. */
+int crab_host_pool_selftest(int callers, int n, int rounds);
+
 /* ---- one-shot forms with the argument lists of the PyO3 functions ------------- */
 /* Each looks up (or creates) a cached engine for (codes pointer, shape, checksum, tree) on `device`. */
 int crab_compute_log_likelihood(int device, int n, const double *q, const double *pi, int n_nodes,

@@ -71,3 +71,66 @@ def test_two_rank_gloo_sum_equals_whole(oracle):
                                                      c["branch_lengths"], None, c["sequences"], leaf_ids(c))
     assert totals[0] == totals[1]                  # rank-ordered sum: identical on every rank
     assert abs(totals[0] - whole) < 1e-9
+
+
+def test_gene_sharding_and_worker_pool():
+    """Config 5 shards by gene: every gene lands on exactly one rank; results come back in order whatever the
+    completion order of the workers."""
+    import threading
+    import time
+    from crabml_amd.dist import gene_shard, map_genes
+    for n, ws in [(10, 3), (7, 8), (0, 2), (64, 8)]:
+        shards = [gene_shard(n, r, ws) for r in range(ws)]
+        assert sorted(g for s in shards for g in s) == list(range(n))
+        assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    with pytest.raises(ValueError):
+        gene_shard(4, 2, 2)
+
+    made, closed, seen = [], [], set()
+    lock = threading.Lock()
+
+    class FakeEngine:
+        def __init__(self):
+            made.append(self)
+            self.busy = False
+
+        def close(self):
+            closed.append(self)
+
+    def fn(e, g):
+        assert not e.busy                      # an engine is never shared by two genes at once
+        e.busy = True
+        time.sleep(0.002 * (5 - g % 5))        # later genes finish first
+        with lock:
+            seen.add(threading.get_ident())
+        e.busy = False
+        return g * g
+
+    out = map_genes(fn, range(23), workers=4, make_engine=FakeEngine)
+    assert out == [g * g for g in range(23)]
+    assert len(made) == 4 and len(closed) == 4 and 1 < len(seen) <= 4
+    assert map_genes(fn, [], workers=4, make_engine=FakeEngine) == []
+
+
+def _table_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crabml_amd.dist import gather_site_table
+        rng = np.random.default_rng(1)
+        full = rng.normal(size=(50, 4))
+        owner = rng.integers(0, world, size=50)           # which rank's pattern slice holds each site
+        local = np.where((owner == rank)[:, None], full, np.nan)
+        got = gather_site_table(local)
+        out[rank] = bool(np.array_equal(got, full))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_of_the_site_by_class_table():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_table_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert all(out[r] for r in range(world))

@@ -623,3 +623,25 @@ def test_beb_grid_integration_at_size(gpu_engine_cls):
     assert np.abs(post - o_post).max() <= 1e-13
     np.testing.assert_allclose(lnfx, o_lnfx, rtol=1e-12)
     assert abs(ln_fx - o_ln_fx) < TOTAL_ATOL * 10      # a sum of 2 000 terms of magnitude ~30: 1e-12 relative
+
+
+def test_many_genes_on_concurrent_engines(gpu_engine_cls, oracle):
+    """Config 5 shape: independent genes, several engines of one GPU at once (crabml_amd.dist.map_genes); every gene's
+    result equals its stand-alone evaluation bit for bit and matches the oracle."""
+    from crabml_amd import synth
+    from crabml_amd.dist import map_genes
+    genes = [synth.make_case("M8" if g % 2 else "M7", 8 + g, 60 + 7 * g, seed=300 + g) for g in range(7)]
+
+    def fn(eng, case):
+        eng.set_tree(case.parent, case.leaf_node_ids)
+        eng.set_alignment(case.codes, n_states=61)
+        return eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths)
+
+    together = map_genes(fn, genes, workers=3, make_engine=lambda: gpu_engine_cls(0))
+    with gpu_engine_cls(0) as eng:
+        alone = [fn(eng, case) for case in genes]      # one engine re-targeted gene after gene
+    assert together == alone
+    for case, lnL in zip(genes, together):
+        ref = oracle.compute_site_class_log_likelihood(list(case.Q), case.proportions, case.pi, case.tree_structure,
+                                                       case.branch_lengths, None, case.codes, case.leaf_node_ids)
+        assert abs(lnL - ref) < TOTAL_ATOL

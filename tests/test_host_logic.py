@@ -405,3 +405,11 @@ def test_quantile_functions_against_scipy_over_the_optimisers_range():
     assert np.array_equal(discretise_omega("beta", 1e-9, -3.0, 5), discretise_omega("beta", 0.005, 0.005, 5))
     with pytest.raises(ValueError):
         discretise_omega("beta", np.nan, 1.0, 5)
+
+
+def test_host_worker_pool_serves_concurrent_callers():
+    """map_genes drives several engines from several host threads: their parallel loops share one pool."""
+    from crabml_amd import _lib
+    lib = _lib.load()
+    for callers, n, rounds in ((1, 11, 50), (4, 11, 200), (16, 63, 100), (8, 1998, 5), (3, 2, 300)):
+        _lib.check(lib.crab_host_pool_selftest(callers, n, rounds))
