@@ -251,7 +251,9 @@ class Pool {
         job.n = n;
         std::unique_lock<std::mutex> lk(m_);
         jobs_.push_back(&job);
-        cv_.notify_all();
+        lk.unlock();
+        cv_.notify_all();   // with the mutex released: the woken threads must not queue up behind their waker
+        lk.lock();
         drain(&job, lk);
         done_cv_.wait(lk, [&] { return job.done == job.n; });
     }
