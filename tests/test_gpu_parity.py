@@ -645,3 +645,55 @@ def test_many_genes_on_concurrent_engines(gpu_engine_cls, oracle):
         ref = oracle.compute_site_class_log_likelihood(list(case.Q), case.proportions, case.pi, case.tree_structure,
                                                        case.branch_lengths, None, case.codes, case.leaf_node_ids)
         assert abs(lnL - ref) < TOTAL_ATOL
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 tree shapes (500 and 1000 taxa) at a number of sites the oracle finishes in seconds
+# ---------------------------------------------------------------------------------------------
+def test_config3_branch_site_500_taxa(gpu_engine_cls, oracle):
+    from crabml_amd import synth
+    case = synth.make_case("ModelA", 500, 600, seed=3)
+    args = (case.qfactors[0], case.qfactors[1], case.omega0, case.omega2, case.site_class_freqs)
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        lnL, site = eng.branch_site(case.Q3, *args, case.pi, case.branch_lengths, case.branch_labels, return_sites=True)
+        P_dev = np.stack([eng.export_transition_matrices(k) for k in range(4)])
+        from_params = eng.codon_branch_site(case.kappa, case.omega0, case.omega2, case.p0, case.p1, case.pi, case.branch_lengths,
+                                            case.branch_labels)
+        dense, gather = eng.last_work()
+        n_pat = eng.n_patterns
+    assert dense == 497 * n_pat * 4 and gather == 500 * n_pat * 4
+    ref, ref_site = oracle.compute_branch_site_log_likelihood(case.Q3[0], case.Q3[1], case.Q3[2], *args, case.pi, case.tree_structure,
+                                                              case.branch_lengths, case.branch_labels, None, case.codes,
+                                                              case.leaf_node_ids, return_sites=True)
+    # the unscaled reference restatement underflows on a 500-taxon tree: compare where it is finite, and
+    # strictly against the staged pruning of the device's own matrices with rescaling everywhere
+    ok = np.isfinite(ref_site) & (ref_site > -600.0)
+    assert ok.any() and _rel(site[ok], ref_site[ok]) <= 1e-8
+    lnf = oracle.site_lnf_from_transition_matrices(P_dev, case.pi, case.tree_structure, case.codes, case.leaf_node_ids)
+    mx = lnf.max(axis=1)
+    staged = mx + np.log((np.exp(lnf - mx[:, None]) * case.site_class_freqs[None, :]).sum(axis=1))
+    assert _rel(site, staged) <= SITE_RTOL
+    assert abs(lnL - staged.sum()) < 1e-6 * 10
+    assert abs(from_params - lnL) < 1e-9 * abs(lnL)
+
+
+def test_config4_free_ratio_1000_taxa(gpu_engine_cls, oracle):
+    from crabml_amd import synth
+    case = synth.make_case("free-ratio", 1000, 400, seed=4)
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        lnL, site = eng.branch(case.Q_per_node, case.pi, case.branch_lengths, no_clamp=True, return_sites=True)
+        P_dev = eng.export_transition_matrices(0)
+        from_params = eng.codon_branch(case.kappa, case.omega_per_node, case.pi, case.branch_lengths, no_clamp=True)
+        n_pat = eng.n_patterns_total
+        # the 8-GPU sharding of this configuration: slices add up
+        parts = 0.0
+    for a, b in zip(np.linspace(0, n_pat, 4).astype(int)[:-1], np.linspace(0, n_pat, 4).astype(int)[1:]):
+        with _engine(gpu_engine_cls, case.parent, case.codes, pattern_begin=int(a), pattern_end=int(b)) as eng:
+            parts += eng.branch(case.Q_per_node, case.pi, case.branch_lengths, no_clamp=True)
+    lnf = oracle.site_lnf_from_transition_matrices(P_dev[None], case.pi, case.tree_structure, case.codes, case.leaf_node_ids)
+    assert _rel(site, lnf[:, 0]) <= SITE_RTOL
+    assert abs(lnL - lnf[:, 0].sum()) < 1e-6 * 10
+    assert abs(parts - lnL) < 1e-7
+    assert abs(from_params - lnL) < 1e-9 * abs(lnL)
+    for v in (0, 500, 1500):   # kernel 1 on a few of the 1 998 per-node matrices
+        np.testing.assert_allclose(P_dev[v], oracle.matrix_exponential(case.Q_per_node[v], case.pi, case.branch_lengths[v]), atol=2e-14, rtol=0)
