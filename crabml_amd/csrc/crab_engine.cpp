@@ -852,7 +852,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
-    launch_build_p(pool.d, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, e->stream);
+    launch_build_p(pool.d, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, true, e->stream);
 
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
@@ -1480,7 +1480,7 @@ int crab_matrix_exponential(int device, int n, const double *Q, const double *pi
         HIP_CHECK(hipMemcpy(d_eig.p, eig.data(), EIG_STRIDE * sizeof(double), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_t.p, &t, sizeof(double), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_id.p, &zero, sizeof(int32_t), hipMemcpyHostToDevice));
-        launch_build_p(d_eig.p, d_id.p, d_t.p, d_P.p, 1, n, nullptr);
+        launch_build_p(d_eig.p, d_id.p, d_t.p, d_P.p, 1, n, false, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpy(Pf.data(), d_P.p, P_ELEMS * sizeof(double), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i)

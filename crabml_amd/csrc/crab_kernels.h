@@ -86,7 +86,7 @@ inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 +
 // For m in [0, M): eigensystem eig + eig_id[m]*EIG_STRIDE, time t_eff[m]; writes P + m*P_ELEMS in
 // fragment order with row sums in column n_states.
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
-                    hipStream_t stream);
+                    bool clamp_negative, hipStream_t stream);
 
 // ---- kernel 2: Felsenstein pruning, whole tree per (pattern tile, class)  ---------------------
 // (replaces likelihood.rs:120-132,176-246 and branch_site_likelihood.rs:222-299)

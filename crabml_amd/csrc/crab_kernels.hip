@@ -41,7 +41,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // P[16w + (l&15)][16jt + 4r + (l>>4)], stored into both images of crab_kernels.h.  (This kernel is ~1 % of an
 // evaluation; the stores are 8-byte scatters.)
 __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__ eig, const int32_t *__restrict__ eig_id,
-                                                      const double *__restrict__ t_eff, double *__restrict__ P, int n_states)
+                                                      const double *__restrict__ t_eff, double *__restrict__ P, int n_states,
+                                                      int clamp_negative)
 {
     const int m = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -64,6 +65,16 @@ __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__
             const double a = Uinv[k * NS + 16 * jt + c];
             acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
         }
+    }
+    // exp(Qt) >= 0; the eigen route leaves entries of -1e-15 where the true value is (near) zero, e.g. everywhere off
+    // the diagonal at t = 0.  The pruning pass rescales each pattern by its largest *positive* entry, so data that such
+    // a matrix makes impossible would otherwise blow negative noise up into infinities: evaluations clamp it to zero
+    // (as PAML does); crab_matrix_exponential returns the raw values like the reference (matrix.rs:88-102).
+    if (clamp_negative) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[jt][r] = acc[jt][r] < 0.0 ? 0.0 : acc[jt][r];
     }
     // row sums over the real states (padded columns are exact zeros)
     double rs = 0.0;
@@ -90,10 +101,10 @@ __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__
 }
 
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
-                    hipStream_t stream)
+                    bool clamp_negative, hipStream_t stream)
 {
     if (M <= 0) return;
-    hipLaunchKernelGGL(build_p_kernel, dim3(M), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states);
+    hipLaunchKernelGGL(build_p_kernel, dim3(M), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0);
 }
 
 // =============================================================================================

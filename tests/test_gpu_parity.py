@@ -697,3 +697,69 @@ def test_config4_free_ratio_1000_taxa(gpu_engine_cls, oracle):
     assert abs(from_params - lnL) < 1e-9 * abs(lnL)
     for v in (0, 500, 1500):   # kernel 1 on a few of the 1 998 per-node matrices
         np.testing.assert_allclose(P_dev[v], oracle.matrix_exponential(case.Q_per_node[v], case.pi, case.branch_lengths[v]), atol=2e-14, rtol=0)
+
+
+def test_random_tree_shapes_sweep(gpu_engine_cls, oracle):
+    """40 random trees with polytomies, unary internal nodes, leaves hanging off the root, zero-length branches, missing
+    data and leaf rows in shuffled order: the device's staged result must equal the oracle's pruning on every site."""
+    from crabml_amd import synth
+    base = synth.make_case("M8", 6, 10, seed=77)
+    K = 3
+    Q, props, pi = base.Q[[0, 6, 10]], np.array([0.5, 0.3, 0.2]), base.pi
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        n_leaves = int(rng.integers(2, 41))
+        # grow a random rooted tree: repeatedly group 1..4 open subtrees under a new node (1 = unary node)
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1 or nxt == n_leaves:
+            k = int(min(len(open_nodes), rng.choice([1, 2, 2, 2, 3, 4])))
+            if len(open_nodes) == 1 and nxt > n_leaves and k == 1 and rng.random() < 0.7:
+                break
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        n_nodes = nxt
+        par = np.array([parent.get(v, -1) for v in range(n_nodes)], dtype=np.int32)
+        bl = rng.exponential(0.08, size=n_nodes)
+        bl[rng.random(n_nodes) < 0.1] = 0.0
+        bl[par < 0] = 0.0
+        S = int(rng.integers(1, 150))
+        codes = rng.integers(0, 61, size=(n_leaves, S)).astype(np.int32)
+        # make sites less random than uniform: copy a column pattern down to half the taxa
+        codes[: n_leaves // 2] = codes[0]
+        codes[rng.random(codes.shape) < 0.05] = 64
+        codes[rng.random(codes.shape) < 0.01] = -1
+        rows = rng.permutation(n_leaves).astype(np.int32)          # alignment row r belongs to leaf node rows[r]
+        ts = [(v, None if par[v] < 0 else int(par[v])) for v in range(n_nodes)]
+        with gpu_engine_cls(0) as eng:
+            eng.set_tree(par, rows)
+            eng.set_alignment(codes, n_states=61)
+            lnL, site = eng.site_classes(Q, props, pi, bl, return_sites=True, no_clamp=True)
+            P_dev = np.stack([eng.export_transition_matrices(k) for k in range(K)])
+        lnf = oracle.site_lnf_from_transition_matrices(P_dev, pi, ts, codes, rows)
+        want = _mixture(lnf, props, clamp=False)
+        finite = np.isfinite(want)
+        assert np.array_equal(finite, np.isfinite(site)), f"trial {trial}"
+        assert _rel(site[finite], want[finite]) <= SITE_RTOL, f"trial {trial}: {n_leaves} leaves, {n_nodes} nodes, {S} sites"
+
+
+def test_impossible_data_on_zero_length_branches_is_zero_not_nan(gpu_engine_cls):
+    """Two different codons joined by zero-length branches have likelihood exactly 0 under any model.  exp(Q 0) from the
+    eigen route (the reference's route too, matrix.rs:88-102) carries entries of +-1e-15 off the diagonal, so what comes
+    out is rounding noise: zero or some 1e-20.  Evaluations clamp the negative entries (kernel 1) so that
+    power-of-two rescaling never turns negative noise into infinities and NaN (found by the random sweep above): the
+    site must come out as "essentially impossible", never NaN, and must not disturb its neighbours."""
+    c = load_case("lysozyme_m2a")
+    parent = np.array([4, 4, 5, 5, 6, 6, -1], dtype=np.int32)
+    bl = np.array([0.0, 0.0, 0.1, 0.2, 0.05, 0.3, 0.0])
+    codes = np.array([[3, 7], [9, 7], [3, 7], [20, 8]], dtype=np.int32)    # site 0: leaves 0 and 1 disagree at distance 0
+    with _engine(gpu_engine_cls, parent, codes) as eng:
+        lnL, site = eng.site_classes(c["Q"], c["proportions"], c["pi"], bl, return_sites=True, no_clamp=True)
+        lnLc, sitec = eng.site_classes(c["Q"], c["proportions"], c["pi"], bl, return_sites=True)
+        bc = eng.site_lnl_by_class(c["Q"], c["pi"], bl, no_clamp=True)
+    assert not np.isnan(site).any() and not np.isnan(bc).any() and not np.isnan(lnL)
+    assert site[0] < -30.0 and np.all(bc[0] < -30.0)            # noise level or exactly zero
+    assert np.isfinite(site[1]) and np.isfinite(bc[1]).all() and -40.0 < site[1] < 0.0
+    assert sitec[1] == site[1] and np.isfinite(lnLc) and LN_TINY - 1e-9 <= sitec[0] < -30.0
