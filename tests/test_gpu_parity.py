@@ -763,3 +763,68 @@ def test_impossible_data_on_zero_length_branches_is_zero_not_nan(gpu_engine_cls)
     assert site[0] < -30.0 and np.all(bc[0] < -30.0)            # noise level or exactly zero
     assert np.isfinite(site[1]) and np.isfinite(bc[1]).all() and -40.0 < site[1] < 0.0
     assert sitec[1] == site[1] and np.isfinite(lnLc) and LN_TINY - 1e-9 <= sitec[0] < -30.0
+
+
+def test_random_state_spaces_models_and_slices_sweep(gpu_engine_cls, oracle):
+    """Random reversible models on 4 / 20 / 61 / 63 states, 1-5 classes, random trees, every entry point of the handle
+    API that the models share (mixture, per class, branch model, pattern slices), each against the oracle."""
+    rng = np.random.default_rng(99)
+    for trial in range(16):
+        n = int(rng.choice([4, 20, 61, 63]))
+        K = int(rng.integers(1, 6))
+        n_leaves = int(rng.integers(3, 25))
+        # random binary-ish tree by random joins
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1:
+            k = int(min(len(open_nodes), rng.choice([2, 2, 3])))
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        n_nodes = nxt
+        par = np.array([parent.get(v, -1) for v in range(n_nodes)], dtype=np.int32)
+        bl = rng.exponential(0.15, size=n_nodes) + 1e-4
+        bl[par < 0] = 0.0
+        pi = rng.dirichlet(3.0 * np.ones(n))
+        Qs = []
+        for _ in range(K):
+            Sx = rng.gamma(1.0, 1.0, size=(n, n))
+            Sx = (Sx + Sx.T) * (rng.random((n, n)) < 0.6)
+            Sx = np.triu(Sx, 1) + np.triu(Sx, 1).T + 1e-3 * (1 - np.eye(n))
+            Qm = Sx * pi[None, :]
+            np.fill_diagonal(Qm, 0.0)
+            np.fill_diagonal(Qm, -Qm.sum(axis=1))
+            Qs.append(Qm / -(pi * np.diag(Qm)).sum() * rng.uniform(0.3, 2.0))
+        Q = np.stack(Qs)
+        props = rng.dirichlet(np.ones(K))
+        S = int(rng.integers(1, 300))
+        # evolve-ish data: a few ancestral states copied with noise, so that sites are not uniformly random
+        anc = rng.integers(0, n, size=S)
+        codes = np.where(rng.random((n_leaves, S)) < 0.6, anc[None, :], rng.integers(0, n, size=(n_leaves, S))).astype(np.int32)
+        codes[rng.random(codes.shape) < 0.03] = n + 3          # missing
+        ts = [(v, None if par[v] < 0 else int(par[v])) for v in range(n_nodes)]
+        leaf = np.arange(n_leaves, dtype=np.int32)
+        with gpu_engine_cls(0) as eng:
+            eng.set_tree(par, leaf)
+            eng.set_alignment(codes, n_states=n)
+            lnL, site = eng.site_classes(Q, props, pi, bl, return_sites=True)
+            bc = eng.site_lnl_by_class(Q, pi, bl)
+            br = eng.branch(np.repeat(Q[:1], n_nodes, axis=0), pi, bl)
+            one = eng.site_classes(Q[:1], [1.0], pi, bl)
+            n_pat = eng.n_patterns_total
+        ref, ref_site = oracle.compute_site_class_log_likelihood(list(Q), props, pi, ts, bl, None, codes, leaf, return_sites=True)
+        ref_bc = oracle.compute_site_log_likelihoods_by_class(list(Q), pi, ts, bl, None, codes, leaf)
+        tag = f"trial {trial}: n={n} K={K} leaves={n_leaves} S={S}"
+        assert abs(lnL - ref) < TOTAL_ATOL, tag
+        assert _rel(site, ref_site) <= 1e-9, tag           # random dense models are well conditioned; eigensolvers still differ
+        assert_by_class_close(bc, ref_bc, tag, rtol=1e-9)
+        assert br == one, tag
+        cut = int(rng.integers(0, n_pat + 1))
+        parts = 0.0
+        for a, b in ((0, cut), (cut, n_pat)):
+            with gpu_engine_cls(0) as eng:
+                eng.set_tree(par, leaf)
+                eng.set_alignment(codes, n_states=n, pattern_begin=a, pattern_end=b)
+                parts += eng.site_classes(Q, props, pi, bl)
+        assert abs(parts - lnL) < 1e-8, tag
