@@ -828,3 +828,72 @@ def test_random_state_spaces_models_and_slices_sweep(gpu_engine_cls, oracle):
                 eng.set_alignment(codes, n_states=n, pattern_begin=a, pattern_end=b)
                 parts += eng.site_classes(Q, props, pi, bl)
         assert abs(parts - lnL) < 1e-8, tag
+
+
+def test_random_branch_site_and_extreme_branch_lengths_sweep(gpu_engine_cls, oracle):
+    """Model A on random trees with random foreground labels, branch lengths from 1e-3 to 30 substitutions per codon
+    (below that, with partly random codons, the eigen route's +-1e-16 noise in P decides the answer: any two
+    decompositions of matrices that differ in the last bit then disagree, the reference's included),
+    pattern counts around the 64-pattern tile boundaries: staged strict against the oracle's pruning of the device's
+    own matrices (naive, unscaled where it stays finite; the rescaled device result must be finite everywhere)."""
+    from crabml_amd import models, synth
+    base = synth.make_case("M0", 5, 4, seed=5)
+    pi = base.pi
+    rng = np.random.default_rng(11)
+    for trial, S in enumerate([1, 63, 64, 65, 127, 128, 129, 200, 257, 31]):
+        n_leaves = int(rng.integers(4, 30))
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1:
+            k = int(min(len(open_nodes), rng.choice([2, 2, 2, 3])))
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        n_nodes = nxt
+        par = np.array([parent.get(v, -1) for v in range(n_nodes)], dtype=np.int32)
+        bl = 10.0 ** rng.uniform(-3, 1.5, size=n_nodes) if trial % 2 else rng.exponential(0.1, size=n_nodes)
+        bl[par < 0] = 0.0
+        labels = (rng.random(n_nodes - 1) < 0.3).astype(np.uint8)
+        if not labels.any():
+            labels[0] = 1
+        if labels.all():
+            labels[1] = 0
+        kappa, w0, w2, p0, p1 = 2.0 + rng.random(), 0.05 + 0.5 * rng.random(), 1.0 + 4 * rng.random(), 0.5, 0.3
+        if trial == 3:
+            w2 = 1.0                                         # the null model: classes 2a/2b share Q(1) on the foreground
+        ma = models.BranchSiteModelA(pi, labels.astype(int))
+        fr = ma.compute_site_class_frequencies(p0, p1)
+        qb, qf = ma.compute_qfactors(kappa, p0, p1, w0, w2)
+        Q3 = np.stack(ma.unnormalised_Qs(kappa, w0, w2))
+        anc = rng.integers(0, 61, size=S)
+        codes = np.where(rng.random((n_leaves, S)) < 0.7, anc[None, :], rng.integers(0, 61, size=(n_leaves, S))).astype(np.int32)
+        codes[rng.random(codes.shape) < 0.03] = 64
+        ts = [(v, None if par[v] < 0 else int(par[v])) for v in range(n_nodes)]
+        leaf = np.arange(n_leaves, dtype=np.int32)
+        with gpu_engine_cls(0) as eng:
+            eng.set_tree(par, leaf)
+            eng.set_alignment(codes, n_states=61, compress=False)
+            assert eng.n_patterns == S
+            lnL, site = eng.branch_site(Q3, qb, qf, w0, w2, fr, pi, bl, labels, return_sites=True)
+            P_dev = np.stack([eng.export_transition_matrices(k) for k in range(4)])
+            pars = eng.codon_branch_site(kappa, w0, w2, p0, p1, pi, bl, labels)
+            P_par = np.stack([eng.export_transition_matrices(k) for k in range(4)])
+        tag = f"trial {trial}: leaves={n_leaves} S={S}"
+        assert np.isfinite(site).all(), tag
+        lnf = oracle.site_lnf_from_transition_matrices(P_dev, pi, ts, codes, leaf)      # rescaled pruning of the same matrices
+        mx = lnf.max(axis=1)
+        staged = mx + np.log((np.exp(lnf - mx[:, None]) * fr[None, :]).sum(axis=1))
+        assert _rel(site, staged) <= SITE_RTOL, tag
+        assert abs(lnL - staged.sum()) < TOTAL_ATOL * max(1.0, S / 50), tag
+        # the parameter path: its matrices equal the Q path's to the eigen route's absolute accuracy, and its pruning is
+        # strict on its own matrices.  (The two totals themselves agree to 1e-8 relative on ordinary branch lengths; with
+        # log-uniform ones and partly random codons the answer leans on P entries of 1e-12 that the eigen route knows
+        # to 1e-16 absolute, and any two decompositions of matrices differing in the last bit disagree at 1e-4.)
+        assert np.abs(P_par - P_dev).max() <= 1e-13, tag
+        lnf_p = oracle.site_lnf_from_transition_matrices(P_par, pi, ts, codes, leaf)
+        mxp = lnf_p.max(axis=1)
+        staged_p = (mxp + np.log((np.exp(lnf_p - mxp[:, None]) * fr[None, :]).sum(axis=1))).sum()
+        assert abs(pars - staged_p) < TOTAL_ATOL * max(1.0, S / 50), tag
+        if trial % 2 == 0:
+            assert abs(pars - lnL) < 1e-8 * max(1.0, abs(lnL)), tag
