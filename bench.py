@@ -106,10 +106,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # Rehearsal on a one-GPU box (never used by the driver): CRAB_BENCH_BACKEND=gloo CRAB_BENCH_SHARE_GPU=1 lets several
+    # ranks share cuda:0 and exchange over gloo, so the multi-rank control flow can be exercised without an 8-GPU node.
+    backend = os.environ.get("CRAB_BENCH_BACKEND", "nccl")
+    if os.environ.get("CRAB_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     case = synth.make_case("M8", N_TAXA, N_SITES, seed=SEED, block=rank)
     eng = Engine(local_rank)
@@ -152,7 +160,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
