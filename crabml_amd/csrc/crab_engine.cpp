@@ -474,6 +474,20 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
             p.any_term = true;
         }
     }
+    // Stack slots are numbered by frame depth, and the inner frames see most of the traffic (100 taxa: 5 / 17 / 9 saves
+    // at depths 0 / 1 / 2; 1000 taxa: 15 / 51 / 110 / 110 / 39).  The kernel keeps the lowest-numbered slots in
+    // registers and the rest in global memory, so renumber the slots by how often they are written, busiest first.
+    {
+        std::vector<int64_t> writes(std::max(1, e->max_depth) + 1, 0);
+        for (const TreeOp &op : e->ops)
+            if ((op.flags & F_PUSH) && op.slot >= 0 && op.slot < (int)writes.size()) ++writes[op.slot];
+        std::vector<int> order(writes.size()), rank(writes.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return writes[a] > writes[b]; });
+        for (size_t r = 0; r < order.size(); ++r) rank[order[r]] = (int)r;
+        for (TreeOp &op : e->ops)
+            if ((op.flags & (F_PUSH | F_POP_MUL)) && op.slot >= 0 && op.slot < (int)rank.size()) op.slot = rank[op.slot];
+    }
     // host program: a GEMM op's arg is the index of the next GEMM op (-1 none)
     int next_gemm_op = -1;
     for (int i = (int)e->ops.size() - 1; i >= 0; --i)
