@@ -477,7 +477,14 @@ __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, un
     const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
     unsigned code[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+    for (int nt = 0; nt < NT; ++nt) {
+#ifdef CRAB_ABLATE_CODES   // timing experiment only (wrong results): no load, so no wait for one either
+        code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
+        (void)r;
+#else
+        code[nt] = r[nt * 16];
+#endif
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
 }
@@ -599,6 +606,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
     const PruneArgs &a = w.a;
 
     while (w.ip < a.n_ops) {
+        PROF_T(9)
         const int il = w.ip & 63;
         if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
         const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
@@ -954,7 +962,7 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
     {
         (void)hipStreamSynchronize(stream);
         static const char *names[12] = {"prologue+root", "gemm wait vmcnt", "gemm barrier", "gemm dma issue + mfma", "gemm pop-mul",
-                                        "leaf gather issue + wait", "leaf multiply", "normalise", "push", "-", "-", "op decode"};
+                                        "leaf gather issue + wait", "leaf multiply", "normalise", "push", "late column issue + loop", "-", "op decode"};
         std::vector<unsigned long long> h((size_t)grid * 4 * 12);
         (void)hipMemcpy(h.data(), d_prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[12] = {0}, all = 0;
