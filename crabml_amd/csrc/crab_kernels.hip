@@ -201,6 +201,11 @@ __device__ __forceinline__ void r_gstore64(void *sbase, unsigned voff)
 {
     asm volatile("global_store_dwordx2 %2, v[%0:%1], %3 offset:%4" ::"n"(S), "n"(S + 1), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+template <int S, int OFF>
+__device__ __forceinline__ void r_gstore128(void *sbase, unsigned voff)
+{
+    asm volatile("global_store_dwordx4 %2, v[%0:%1], %3 offset:%4" ::"n"(S), "n"(S + 3), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- tile-wide operations ----
@@ -248,39 +253,28 @@ __device__ __forceinline__ void t_gather_seq(const void *sbase, unsigned voff, s
 {
     (r_gload128<D + 4 * Q, 64 * Q>(sbase, voff), ...);
 }
-// stack slot <-> tile: element e of the tile sits 512 bytes after element e-1 (64 lanes x 8 bytes per element);
-// the instruction offset reaches 4 KiB, so every eighth element starts a new lane offset
-template <int D, int E0, int... I>
-__device__ __forceinline__ void t_load8(const void *sbase, unsigned voff, std::integer_sequence<int, I...>)
+// stack slot <-> tile.  A saved tile is laid out like a block of 16 gather-image columns (pattern c at c * 512 bytes,
+// the lane's 16-byte piece q at 64 q + 16 g; voff = (lane & 15) * 512 + (lane >> 4) * 16): eight 16-byte accesses per
+// lane.  (In this layout a pop can also ride inside the product that precedes it, through Ride::img_b; measured
+// neutral -- the other wave of the SIMD already covers the load -- and left out.)
+template <int S, int... Q>
+__device__ __forceinline__ void t_scatter_seq(void *sbase, unsigned voff, std::integer_sequence<int, Q...>)
 {
-    (r_gload64<D + 2 * (E0 + I), 512 * I>(sbase, voff), ...);
-}
-template <int S, int E0, int... I>
-__device__ __forceinline__ void t_store8(void *sbase, unsigned voff, std::integer_sequence<int, I...>)
-{
-    (r_gstore64<S + 2 * (E0 + I), 512 * I>(sbase, voff), ...);
+    (r_gstore128<S + 4 * Q, 64 * Q>(sbase, voff), ...);
 }
 template <int NT, int D>
 __device__ __forceinline__ void t_load(const void *sbase, unsigned voff)
 {
     using S8 = std::make_integer_sequence<int, 8>;
-    t_load8<D, 0>(sbase, voff, S8{});
-    t_load8<D, 8>(sbase, voff + 4096, S8{});
-    if constexpr (NT == 2) {
-        t_load8<D, 16>(sbase, voff + 8192, S8{});
-        t_load8<D, 24>(sbase, voff + 12288, S8{});
-    }
+    t_gather_seq<D>(sbase, voff, S8{});
+    if constexpr (NT == 2) t_gather_seq<D + 32>(sbase, voff + 8192, S8{});
 }
 template <int NT, int S>
 __device__ __forceinline__ void t_store(void *sbase, unsigned voff)
 {
     using S8 = std::make_integer_sequence<int, 8>;
-    t_store8<S, 0>(sbase, voff, S8{});
-    t_store8<S, 8>(sbase, voff + 4096, S8{});
-    if constexpr (NT == 2) {
-        t_store8<S, 16>(sbase, voff + 8192, S8{});
-        t_store8<S, 24>(sbase, voff + 12288, S8{});
-    }
+    t_scatter_seq<S>(sbase, voff, S8{});
+    if constexpr (NT == 2) t_scatter_seq<S + 32>(sbase, voff + 8192, S8{});
 }
 
 // Largest high word over the 16 elements of group nt (conditional likelihoods are non-negative, so the largest
@@ -461,7 +455,7 @@ struct Walk {
     char *stack;               // this wave's stack area (uniform) ...
     int32_t *stack_e;          // ... and this lane's element of its exponent area
     int estk[3][NT];           // exponents of the register-resident stack slots (first NSTK used)
-    unsigned lane_off8;        // lane * 8
+    unsigned stack_voff;       // this lane's byte offset inside a saved tile: (lane & 15) * 512 + (lane >> 4) * 16
     unsigned lds_a;            // LDS byte address of this lane's A operand inside a tile pair
     char *smem;
     int wave, lane;
@@ -554,7 +548,7 @@ __device__ __forceinline__ void push(Walk<NT> &w, int slot, const int (&eX)[NT])
     int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eX[nt];
-    t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+    t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.stack_voff);
 }
 // Y *= stack[slot]; the dead tile L is the landing zone when the slot is in global memory.
 template <int NT, int Y, int L>
@@ -587,7 +581,7 @@ __device__ __forceinline__ void pop_mul(Walk<NT> &w, int slot, int (&eY)[NT])
     int es[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) es[nt] = se[nt * 64];
-    t_load<NT, L>(w.stack + (size_t)slot * slot_bytes, w.lane_off8);
+    t_load<NT, L>(w.stack + (size_t)slot * slot_bytes, w.stack_voff);
     r_wait_vm0();
     t_mul<NT, Y, L>();
 #pragma unroll
@@ -777,7 +771,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.gather0 = (const char *)(a.P + P_IMAGE);
         w.stack = (char *)a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_bytes;
         w.stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;
-        w.lane_off8 = lane * 8;
+        w.stack_voff = (unsigned)(lane & 15) * 512u + (unsigned)(lane >> 4) * 16u;
         w.lds_a = (unsigned)(size_t)LDS_PTR(smem) + (g * 4 + (lane & 3)) * 16;
         w.smem = smem;
         w.wave = wave;

@@ -12,4 +12,4 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $FLAGS -o $D/crabml_amd
 cp ${CRAB_SCRIPT:-scripts/gpu_time_c2.py} $D/t.py
 sed -i "s#sys.path.insert(0, .*#sys.path.insert(0, \"$D\")#" $D/t.py
 cd $D
-echo "variant [$FLAGS]: $(timeout -k 10 120 python t.py "$@" 2>&1 | tail -1)"
+echo "variant [$FLAGS]: $(timeout -k 10 300 python t.py "$@" 2>&1 | tail -1)"
