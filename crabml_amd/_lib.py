@@ -41,6 +41,7 @@ SIGNATURES = {
                                         C.c_uint, dp, dp]),
     "crab_eval_branch": (C.c_int, [vp, C.c_int, dp, dp, dp, C.c_int, C.c_uint, dp, dp]),
     "crab_eval_codon_site_classes": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp]),
+    "crab_eval_codon_class_posteriors": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_uint, dp]),
     "crab_eval_codon_branch": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, C.c_uint, dp]),
     "crab_eval_codon_branch_site": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, bp, C.c_int, C.c_uint, dp]),
     "crab_build_site_class_q_matrices": (C.c_int, [C.c_int, C.c_double, dp, dp, dp, dp]),

@@ -63,3 +63,19 @@ def m2a_site_posteriors(engine, kappa, pi, mle_proportions, mle_omegas, branch_l
     cols, props = paml_grid_m2a(n1d)
     post, _, ln_fx = engine.beb_grid(Q, pi, branch_lengths, cols, props)
     return post, ln_fx
+
+
+def site_posteriors_over_grid(engine, class_parameters, weights, pi, branch_lengths, batch: int = 64):
+    """The adaptive-grid path, ``BEBCalculator.compute_site_posteriors`` (beb.py:663-731): ``class_parameters`` is one
+    (kappa, omegas[K], proportions[K]) triple per grid point -- what ``model_class(**params).get_site_classes()`` gives
+    -- and ``weights`` the grid weights.  Grid points go to the device ``batch`` at a time; the accumulation over the
+    grid happens there (kernel ``class_posteriors_kernel``), only [n_sites, K] comes back per batch."""
+    total = None
+    for lo in range(0, len(class_parameters), batch):
+        chunk = class_parameters[lo:lo + batch]
+        ka = np.array([c[0] for c in chunk], dtype=np.float64)
+        om = np.array([c[1] for c in chunk], dtype=np.float64)
+        pr = np.array([c[2] for c in chunk], dtype=np.float64)
+        part = engine.codon_class_posteriors(ka, om, pr, np.asarray(weights[lo:lo + batch], dtype=np.float64), pi, branch_lengths)
+        total = part if total is None else total + part
+    return total

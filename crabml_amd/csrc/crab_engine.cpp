@@ -717,6 +717,8 @@ struct EvalPlan {
         double *ln_fx = nullptr;        // out: ln f(X) = logsumexp_g lnfx[g]
     };
     const Beb *beb = nullptr;
+    const double *post_weights = nullptr;   // [n_groups]: weighted class posteriors instead of a likelihood (kernel 4b)
+    double *post_out = nullptr;             // out [n_sites][K / n_groups]
 };
 
 void check_ready(crab_engine *e)
@@ -893,8 +895,17 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
     e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0) +
-                    (pl.beb ? (size_t)2 * pl.beb->G + (size_t)e->n_pat * pl.beb->n_mix : 0));
-    if (pl.beb) {
+                    (pl.beb ? (size_t)2 * pl.beb->G + (size_t)e->n_pat * pl.beb->n_mix : 0) +
+                    (pl.post_weights ? (size_t)e->n_pat * (pl.K / G) : 0));
+    if (pl.post_weights) {
+        const int Kc = pl.K / G;
+        e->d_beb_w.ensure(G);
+        e->d_beb_post.ensure((size_t)std::max<int64_t>(1, e->n_pat) * Kc);
+        HIP_CHECK(hipMemcpyAsync(e->d_beb_w.p, pl.post_weights, G * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        launch_class_posteriors(e->d_f.p, e->d_e.p, G, Kc, e->n_pat, e->n_pat_pad, e->d_props.p, e->d_beb_w.p, e->d_beb_post.p, e->stream);
+        if (e->n_pat > 0)
+            HIP_CHECK(hipMemcpyAsync(e->h_out.p + G, e->d_beb_post.p, (size_t)e->n_pat * Kc * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    } else if (pl.beb) {
         const EvalPlan::Beb &bb = *pl.beb;
         const size_t gm = (size_t)bb.G * bb.n_mix;
         e->d_beb_F.ensure((size_t)pl.K * e->n_pat_pad);
@@ -997,7 +1008,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
     e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
 
-    if (pl.beb) {
+    if (pl.post_weights) {
+        const double *src = e->h_out.p + G;
+        const int Kc = pl.K / G;
+        for (int64_t s = 0; s < e->n_sites; ++s) {
+            const int64_t p = e->site_to_pat[s];
+            if (p < e->pat_begin || p >= e->pat_end) continue;
+            std::memcpy(pl.post_out + (size_t)s * Kc, src + (size_t)(p - e->pat_begin) * Kc, Kc * sizeof(double));
+        }
+    } else if (pl.beb) {
         const double *src = e->h_out.p + G + 2 * (size_t)pl.beb->G;
         const int nm = pl.beb->n_mix;
         for (int64_t s = 0; s < e->n_sites; ++s) {
@@ -1582,6 +1601,39 @@ void build_site_class_qs(int K, double kappa, const double *omegas, const double
     for (size_t i = 0; i < (size_t)K * 61 * 61; ++i) Q[i] /= scale;
 }
 
+// distinct unnormalised matrices Q(kappa_b, omega_bk); the mixture's shared scale sum_k p_k mu_k
+// (e.g. models/codon.py:709-729) divides the branch lengths instead of the matrices.  bl_stride = n_nodes for one
+// vector of branch lengths per parameter vector, 0 for one shared by all.
+void plan_codon_site_classes(crab_engine *e, EvalPlan &pl, int B, int K, const double *kappa, const double *omegas,
+                             const double *proportions, const double *pi, const double *branch_lengths, size_t bl_stride)
+{
+    const int nn = e->n_nodes;
+    QPool qp;
+    pl.n_groups = B;
+    pl.K = B * K;
+    pl.M = B * K * nn;
+    pl.eig_id.resize(pl.M);
+    pl.t_eff.resize(pl.M);
+    pl.pidx.resize((size_t)pl.K * nn);
+    for (int b = 0; b < B; ++b) {
+        double scale = 0.0;
+        for (int k = 0; k < K; ++k) scale += proportions[(size_t)b * K + k] * codon_mean_rate(kappa[b], omegas[(size_t)b * K + k], pi);
+        if (!(scale > 0.0)) fail(CRAB_ERR_ARG, "site-class rate matrices have zero mean rate");
+        for (int k = 0; k < K; ++k) {
+            const int q = qp.get(kappa[b], omegas[(size_t)b * K + k]);
+            for (int v = 0; v < nn; ++v) {
+                const int m = (b * K + k) * nn + v;
+                pl.eig_id[m] = q;
+                pl.t_eff[m] = v == e->root ? 0.0 : branch_lengths[(size_t)b * bl_stride + v] / scale;
+                pl.pidx[m] = m;
+            }
+        }
+    }
+    pl.kw = qp.keys;
+    pl.n_eig = (int)qp.keys.size();
+    pl.props.assign(proportions, proportions + (size_t)B * K);
+}
+
 // Model A's class frequencies [p0, p1, p2 p0/(p0+p1), p2 p1/(p0+p1)] (codon_branch_site.py:108-161) and Qfactors
 // 1 / mean rate at the branch type's average omega (:163-231)
 void model_a_quantities(double kappa, double omega0, double omega2, double p0, double p1, const double *pi, double *freqs, double *qfactors)
@@ -1652,36 +1704,31 @@ int crab_eval_codon_site_classes(crab_engine *e, int B, int K, const double *kap
             fail(CRAB_ERR_ARG, "crab_eval_codon_site_classes: bad arguments");
         if (e->n_states != 61) fail(CRAB_ERR_ARG, "codon-model entry points need a 61-state alignment");
         for (int b = 0; b < B; ++b) check_params("crab_eval_codon_site_classes", kappa[b], omegas + (size_t)b * K, K);
-        // distinct unnormalised matrices Q(kappa_b, omega_bk); the mixture's shared scale sum_k p_k mu_k
-        // (e.g. models/codon.py:709-729) divides the branch lengths instead of the matrices
-        const int nn = e->n_nodes;
-        QPool qp;
         EvalPlan pl;
-        pl.n_groups = B;
-        pl.K = B * K;
-        pl.M = B * K * nn;
-        pl.eig_id.resize(pl.M);
-        pl.t_eff.resize(pl.M);
-        pl.pidx.resize((size_t)pl.K * nn);
-        for (int b = 0; b < B; ++b) {
-            double scale = 0.0;
-            for (int k = 0; k < K; ++k) scale += proportions[(size_t)b * K + k] * codon_mean_rate(kappa[b], omegas[(size_t)b * K + k], pi);
-            if (!(scale > 0.0)) fail(CRAB_ERR_ARG, "site-class rate matrices have zero mean rate");
-            for (int k = 0; k < K; ++k) {
-                const int q = qp.get(kappa[b], omegas[(size_t)b * K + k]);
-                for (int v = 0; v < nn; ++v) {
-                    const int m = (b * K + k) * nn + v;
-                    pl.eig_id[m] = q;
-                    pl.t_eff[m] = v == e->root ? 0.0 : branch_lengths[(size_t)b * nn + v] / scale;
-                    pl.pidx[m] = m;
-                }
-            }
-        }
-        pl.kw = qp.keys;
-        pl.n_eig = (int)qp.keys.size();
-        pl.props.assign(proportions, proportions + (size_t)B * K);
+        plan_codon_site_classes(e, pl, B, K, kappa, omegas, proportions, pi, branch_lengths, e->n_nodes);
         pl.mix_mode = (flags & CRAB_FLAG_NO_CLAMP) ? MIX_LOGSUMEXP_NOCLAMP : MIX_LOGSUMEXP_CLAMP;
         run_plan(e, pl, pi, lnL, nullptr, nullptr);
+    });
+}
+
+int crab_eval_codon_class_posteriors(crab_engine *e, int B, int K, const double *kappa, const double *omegas, const double *proportions,
+                                     const double *weights, const double *pi, const double *branch_lengths, unsigned flags,
+                                     double *posteriors)
+{
+    (void)flags;
+    if (!e) return CRAB_ERR_ARG;
+    return guarded(e, [&] {
+        check_ready(e);
+        if (B < 1 || K < 1 || !kappa || !omegas || !proportions || !weights || !pi || !branch_lengths || !posteriors)
+            fail(CRAB_ERR_ARG, "crab_eval_codon_class_posteriors: bad arguments");
+        if (K > POST_MAX_K) fail(CRAB_ERR_ARG, "crab_eval_codon_class_posteriors: at most 32 classes");
+        if (e->n_states != 61) fail(CRAB_ERR_ARG, "codon-model entry points need a 61-state alignment");
+        for (int b = 0; b < B; ++b) check_params("crab_eval_codon_class_posteriors", kappa[b], omegas + (size_t)b * K, K);
+        EvalPlan pl;
+        plan_codon_site_classes(e, pl, B, K, kappa, omegas, proportions, pi, branch_lengths, 0);
+        pl.post_weights = weights;
+        pl.post_out = posteriors;
+        run_plan(e, pl, pi, nullptr, nullptr, nullptr);
     });
 }
 

@@ -167,6 +167,12 @@ struct BebArgs {
     const double *grid_w;     // [G] in to stage 3
     double *post;             // [n_pat][n_mix] out of stage 3
 };
+// Weighted class posteriors over a list of parameter vectors (analysis/beb.py:698-729): group b holds the K class
+// likelihoods of parameter vector b; out[p][k] = sum_b w_b * p_bk f_bk(p) / max(sum_k p_bk f_bk(p), 1e-300) with
+// f = max(f, 1e-300) as compute_site_log_likelihoods_by_class returns it.  Groups are added in order (deterministic).
+constexpr int POST_MAX_K = 32;
+void launch_class_posteriors(const double *f, const int32_t *e, int n_groups, int K, int64_t n_pat, int64_t n_pat_pad,
+                             const double *props, const double *weights, double *out, hipStream_t stream);
 void launch_beb_scale(const BebArgs &a, hipStream_t stream);
 void launch_beb_grid_lnf(const BebArgs &a, hipStream_t stream);
 void launch_beb_posteriors(const BebArgs &a, hipStream_t stream);

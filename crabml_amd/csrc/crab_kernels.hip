@@ -1185,6 +1185,50 @@ __global__ __launch_bounds__(256) void beb_posterior_kernel(BebArgs a)
         }
 }
 
+// one thread per pattern; the parameter vectors are added in order
+__global__ __launch_bounds__(256) void class_posteriors_kernel(const double *__restrict__ f, const int32_t *__restrict__ e, int n_groups,
+                                                               int K, long long n_pat, long long n_pat_pad,
+                                                               const double *__restrict__ props, const double *__restrict__ weights,
+                                                               double *__restrict__ out)
+{
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pat) return;
+    double acc[POST_MAX_K];
+#pragma unroll
+    for (int k = 0; k < POST_MAX_K; ++k) acc[k] = 0.0;
+    for (int b = 0; b < n_groups; ++b) {
+        double lik[POST_MAX_K], row = 0.0;
+#pragma unroll
+        for (int k = 0; k < POST_MAX_K; ++k) {
+            lik[k] = 0.0;
+            if (k < K) {
+                const size_t o = ((size_t)b * K + k) * n_pat_pad + p;
+                const int ex = e[o];
+                double v = ex < -1100 ? 0.0 : ldexp(f[o], ex > 1100 ? 1100 : ex);
+                v = v > 1e-300 ? v : 1e-300;   // exp(ln max(f, 1e-300)) (likelihood.rs:328-335, beb.py:718)
+                lik[k] = v * props[(size_t)b * K + k];
+                row += lik[k];
+            }
+        }
+        row = row > 1e-300 ? row : 1e-300;     // beb.py:724-725
+        const double w = weights[b] / row;
+#pragma unroll
+        for (int k = 0; k < POST_MAX_K; ++k)
+            if (k < K) acc[k] += w * lik[k];
+    }
+#pragma unroll
+    for (int k = 0; k < POST_MAX_K; ++k)
+        if (k < K) out[(size_t)p * K + k] = acc[k];
+}
+
+void launch_class_posteriors(const double *f, const int32_t *e, int n_groups, int K, int64_t n_pat, int64_t n_pat_pad,
+                             const double *props, const double *weights, double *out, hipStream_t stream)
+{
+    if (n_pat <= 0) return;
+    hipLaunchKernelGGL(class_posteriors_kernel, dim3((unsigned)((n_pat + 255) / 256)), dim3(256), 0, stream, f, e, n_groups, K,
+                       (long long)n_pat, (long long)n_pat_pad, props, weights, out);
+}
+
 void launch_beb_scale(const BebArgs &a, hipStream_t stream)
 {
     if (a.n_pat <= 0) return;

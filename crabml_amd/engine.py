@@ -229,6 +229,23 @@ class Engine:
                                                            L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, out.ctypes.data_as(L.dp)))
         return float(out[0]) if single else out
 
+    def codon_class_posteriors(self, kappa, omegas, proportions, weights, pi, branch_lengths):
+        """[n_sites, K] class posteriors averaged over B weighted parameter vectors (analysis/beb.py:698-729):
+        kappa, weights [B]; omegas, proportions [B, K]; branch_lengths [n_nodes] shared by all vectors."""
+        ka = self._batch(kappa, name="kappa")
+        B = len(ka)
+        om = np.ascontiguousarray(np.asarray(omegas, dtype=np.float64)).reshape(B, -1)
+        K = om.shape[1]
+        pr = self._batch(proportions, B, K, "proportions")
+        w = self._batch(weights, B, name="weights")
+        bl, blp = self._bl(branch_lengths)
+        pi_, pp = self._pi(pi)
+        out = np.full((self.n_sites, K), np.nan)
+        self._check(self._lib.crab_eval_codon_class_posteriors(self._h, B, K, ka.ctypes.data_as(L.dp), om.ctypes.data_as(L.dp),
+                                                               pr.ctypes.data_as(L.dp), w.ctypes.data_as(L.dp), pp, blp, 0,
+                                                               out.ctypes.data_as(L.dp)))
+        return out
+
     def codon_branch(self, kappa, omega_per_node, pi, branch_lengths, no_clamp=False):
         """Branch model from (kappa, one omega per node); batched like codon_site_classes."""
         single = np.ndim(kappa) == 0

@@ -150,6 +150,15 @@ int crab_eval_codon_branch_site(crab_engine *e, int B, const double *kappa, cons
 int crab_build_site_class_q_matrices(int K, double kappa, const double *omegas, const double *proportions,
                                      const double *pi, double *Q_out);
 
+/* Class posteriors of every site averaged over a weighted list of parameter vectors: what
+ * BEBCalculator.compute_site_posteriors (analysis/beb.py:663-731, the adaptive-grid path) accumulates in Python, one
+ * compute_site_log_likelihoods call and one [n_sites, K] table per grid point.  For vector b: lik_k = max(f_k, 1e-300) p_bk
+ * (:718-721), normalised over the classes with the row sum floored at 1e-300 (:724-726), added with weight w_b (:729).
+ * kappa, weights: [B]; omegas, proportions: [B][K] (K <= 32); branch_lengths: [n_nodes], shared (the reference fixes
+ * them at the MLE); posteriors: [n_sites][K].  Call it once per batch of grid points and add the results. */
+int crab_eval_codon_class_posteriors(crab_engine *e, int B, int K, const double *kappa, const double *omegas,
+                                     const double *proportions, const double *weights, const double *pi,
+                                     const double *branch_lengths, unsigned flags, double *posteriors);
 /* The quantile step of the discrete-distribution models: omegas_out[j] = ppf((2j+1)/(2K)), j in [0, K), of
  * beta(a, b) (kind 0: M7 / M8 / M8a, models/codon.py:597-604, 694-701, 795-802) or of gamma(shape a, rate b)
  * (kind 1: M5, :892-899), shape parameters floored at 0.005 like the reference (:570-571, :864-865).  Replaces the

@@ -96,3 +96,17 @@ def site_posteriors(site_log_liks, cols, props, weights=None, chunk=256):
             keep = ok & ~(terms[c] < 1e-300)
             post[lo:lo + chunk, c] = (np.where(keep, terms[c] / safe, 0.0) * gw[None, :]).sum(axis=1)
     return post, lnfXs, fX
+
+
+def site_posteriors_weighted(tables, proportions, weights):
+    """beb.py:689-731 (the adaptive-grid accumulation): ``tables[b]`` is the [S, K] table of ln max(f, 1e-300) the
+    reference gets from compute_site_log_likelihoods at grid point b (:712), ``proportions[b]`` its class proportions,
+    ``weights[b]`` the grid weight.  Statement for statement."""
+    post = None
+    for lnf, props, w in zip(tables, proportions, weights):
+        site_liks = np.exp(np.asarray(lnf, dtype=np.float64))            # :718
+        site_liks = site_liks * np.asarray(props, dtype=np.float64)[None, :]   # :720-721
+        row_sums = np.maximum(site_liks.sum(axis=1, keepdims=True), 1e-300)     # :724-725
+        contrib = w * (site_liks / row_sums)                            # :726-729
+        post = contrib if post is None else post + contrib
+    return post

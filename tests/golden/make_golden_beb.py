@@ -79,6 +79,40 @@ def main():
                         Q=captured["Q"], site_log_liks=captured["site_log_liks"],
                         grid_p0=grid[:, 3], grid_p1=grid[:, 4], grid_omega0=grid[:, 1], grid_omega2=grid[:, 2],
                         posteriors_ref=post)
+    # ---- the adaptive-grid accumulation, BEBCalculator.compute_site_posteriors (beb.py:663-731), on a small
+    #      hand-made grid around the MLE (the reference derives its grid from a Hessian; the accumulation is what is
+    #      pinned here), with M8 so that the beta quantile step is inside the reference's model class ----
+    mle8 = dict(kappa=5.029752, p0=0.868486, p_beta=9.517504, q_beta=13.543157, omega_s=4.370617)
+    tables = []
+
+    class Calc8:
+        def compute_site_log_likelihoods(self, Q_matrices, pi_, proportions):
+            out = orc.compute_site_log_likelihoods_by_class(list(Q_matrices), pi_, ts, bl, None, seq, leaf)
+            tables.append(out.copy())
+            return out
+
+    c8 = beb.BEBCalculator.__new__(beb.BEBCalculator)
+    c8.mle_params = dict(mle8, ncatG=10)
+    c8.alignment = calc.alignment
+    c8.model_class = codon.M8CodonModel
+    c8.param_names = ["kappa", "p0", "p_beta", "q_beta", "omega_s"]
+    c8.pi = pi
+    c8.calc = Calc8()
+    c8.mle_model = codon.M8CodonModel(**c8.mle_params, pi=pi)
+    rng = np.random.default_rng(8)
+    base = np.array([mle8[k] for k in c8.param_names])
+    pts = [base] + [base * np.exp(rng.normal(0.0, 0.15, size=5)) for _ in range(8)]
+    for p_ in pts:
+        p_[1] = min(p_[1], 0.99)
+    wts = rng.dirichlet(np.ones(len(pts)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        post8 = c8.compute_site_posteriors(pts, list(wts))
+    cls = [codon.M8CodonModel(**c8._array_to_params(p_), pi=pi).get_site_classes() for p_ in pts]
+    np.savez_compressed(os.path.join(HERE, "lysozyme_m8_beb_grid.npz"),
+                        pi=pi, parent=parent, branch_lengths=bl, sequences=seq, grid_points=np.asarray(pts), weights=wts,
+                        grid_kappa=np.asarray([p_[0] for p_ in pts]), grid_omegas=np.asarray([c[1] for c in cls]),
+                        grid_proportions=np.asarray([c[0] for c in cls]), tables=np.asarray(tables), posteriors_ref=post8)
+    print("adaptive-path fixture:", post8.shape, "row sums", post8.sum(axis=1)[:3])
     print("posterior P(omega>1) of the sites PAML lists (15 17 37 41 50 62 114 126):",
           np.round(post[[14, 16, 36, 40, 49, 61, 113, 125], 2], 3))
 

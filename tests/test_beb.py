@@ -67,3 +67,18 @@ def test_oracle_loop_form_equals_vectorised_form(beb_case):
     wts = np.array([2, 2, 2, 2, 1, 1, 1, 1, 1], dtype=float)
     np.testing.assert_allclose(obeb.site_posteriors(dup, cols[pick], props[pick])[1],
                                obeb.site_posteriors(lnf, cols[pick], props[pick], weights=wts)[1], rtol=1e-13)
+
+
+def test_oracle_reproduces_the_reference_adaptive_grid_accumulation():
+    """compute_site_posteriors (beb.py:663-731) on nine M8 grid points: the restatement against the reference's output,
+    from the very tables the reference was handed; and the class omegas the device path would be given (quantiles from
+    crab_discretise_omega) against the ones the reference's model class produced with scipy."""
+    from crabml_amd.engine import discretise_omega
+    from oracle import beb as obeb
+    c = load_case("lysozyme_m8_beb_grid")
+    post = obeb.site_posteriors_weighted(c["tables"], c["grid_proportions"], c["weights"])
+    assert np.abs(post - c["posteriors_ref"]).max() <= 1e-15
+    np.testing.assert_allclose(post.sum(axis=1), c["weights"].sum(), atol=1e-13)
+    for pt, om in zip(c["grid_points"], c["grid_omegas"]):
+        got = np.append(discretise_omega("beta", pt[2], pt[3], 10), max(pt[4], 1.001))
+        np.testing.assert_allclose(got, om, rtol=1e-12, atol=0)

@@ -897,3 +897,28 @@ def test_random_branch_site_and_extreme_branch_lengths_sweep(gpu_engine_cls, ora
         mxp = lnf_p.max(axis=1)
         staged_p = (mxp + np.log((np.exp(lnf_p - mxp[:, None]) * fr[None, :]).sum(axis=1))).sum()
         assert abs(pars - staged_p) < TOTAL_ATOL * max(1.0, S / 50), tag
+
+
+def test_beb_adaptive_grid_accumulation_against_the_reference(gpu_engine_cls):
+    """BEBCalculator.compute_site_posteriors (analysis/beb.py:663-731): nine weighted M8 grid points accumulated on the
+    device, from parameters (quantiles and rate matrices built behind the boundary), against the reference's output."""
+    from crabml_amd import beb
+    from crabml_amd.engine import build_site_class_q_matrices, discretise_omega
+    from oracle import beb as obeb
+    c = load_case("lysozyme_m8_beb_grid")
+    params = [(pt[0], np.append(discretise_omega("beta", pt[2], pt[3], 10), max(pt[4], 1.001)), pr)
+              for pt, pr in zip(c["grid_points"], c["grid_proportions"])]
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        post = beb.site_posteriors_over_grid(eng, params, c["weights"], c["pi"], c["branch_lengths"], batch=4)   # 4 + 4 + 1
+        once = beb.site_posteriors_over_grid(eng, params, c["weights"], c["pi"], c["branch_lengths"], batch=64)
+        tables = [eng.site_lnl_by_class(build_site_class_q_matrices(k, om, pr, c["pi"]), c["pi"], c["branch_lengths"])
+                  for k, om, pr in params]
+        with pytest.raises(ValueError, match="at most 32"):
+            eng.codon_class_posteriors([2.0], np.linspace(0.1, 2, 33)[None], np.full((1, 33), 1 / 33), [1.0], c["pi"], c["branch_lengths"])
+    ref = c["posteriors_ref"]
+    big = ref > 1e-8
+    assert np.abs(post - ref).max() <= 1e-11 and np.abs(post[big] / ref[big] - 1.0).max() <= 1e-9
+    assert np.abs(once - post).max() <= 1e-15                       # batching only changes where the partial sums are added
+    strict = obeb.site_posteriors_weighted(tables, c["grid_proportions"], c["weights"])   # the device's own tables through the oracle
+    assert np.abs(post[big] / strict[big] - 1.0).max() <= 1e-9 and np.abs(post - strict).max() <= 1e-12
+    np.testing.assert_allclose(post.sum(axis=1), c["weights"].sum(), atol=1e-12)
