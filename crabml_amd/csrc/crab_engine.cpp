@@ -1891,7 +1891,22 @@ crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t 
         return nullptr;
     }
     CacheKey key{device, n_leaves, n_sites, n_states, 0, 0};
-    key.data_hash = hash_words(codes, (size_t)n_leaves * n_sites * sizeof(int32_t), 1);
+    // the stateless boundary hands the alignment over on every call (4 MB at C2): hash it in 256 KiB chunks on the
+    // host pool, then hash the chunk hashes
+    {
+        const size_t bytes = (size_t)n_leaves * n_sites * sizeof(int32_t), chunk = 256 * 1024;
+        const int n_chunks = (int)((bytes + chunk - 1) / chunk);
+        if (n_chunks <= 1) {
+            key.data_hash = hash_words(codes, bytes, 1);
+        } else {
+            std::vector<uint64_t> part(n_chunks);
+            parallel_for(n_chunks, [&](int i) {
+                const size_t lo = (size_t)i * chunk;
+                part[i] = hash_words((const char *)codes + lo, std::min(chunk, bytes - lo), 1 + (uint64_t)i);
+            });
+            key.data_hash = hash_words(part.data(), part.size() * sizeof(uint64_t), bytes);
+        }
+    }
     uint64_t th = hash_words(parents, (size_t)n_nodes * sizeof(int32_t), 2);
     if (node_ids) th = mix64(th, hash_words(node_ids, (size_t)n_nodes * sizeof(int32_t), 3));
     if (leaf_ids) th = mix64(th, hash_words(leaf_ids, (size_t)n_leaves * sizeof(int32_t), 4));
