@@ -88,15 +88,25 @@ __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__
     const int ns_jt = n_states >> 4, ns_r = (n_states >> 2) & 3, ns_g = n_states & 3;
     double *out = P + (size_t)m * P_ELEMS;
     const int i = 16 * mt + c;
+    // 16-byte stores.  Operand image: registers r, r+1 (r even) of a lane are neighbours there (the (j>>2)&1 bit).
+    // Gather image: rows i and i^4 are neighbours (the (i>>2)&1 bit) and live in lanes c and c^4, so each pair of lanes
+    // swaps one value per register pair: the lane with bit 2 of c clear stores column j(r), the other column j(r+1).
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const bool hi_half = (c & 4) != 0;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double v = acc[jt][r];
-            if (jt == ns_jt && r == ns_r && g == ns_g) v = rs;
-            const int j = 16 * jt + 4 * r + g;
-            out[p_operand_index(i, j)] = v;
-            out[p_gather_index(i, j)] = v;
+        for (int r = 0; r < 4; r += 2) {
+            double v0 = acc[jt][r], v1 = acc[jt][r + 1];
+            if (jt == ns_jt && r == ns_r && g == ns_g) v0 = rs;
+            if (jt == ns_jt && r + 1 == ns_r && g == ns_g) v1 = rs;
+            const int j0 = 16 * jt + 4 * r + g, j1 = j0 + 4;
+            *(v2d *)(out + p_operand_index(i, j0)) = (v2d){v0, v1};
+            // what the partner lane (c ^ 4) needs from this lane: its column is j1 if this lane is the low half, j0 otherwise
+            const double give = hi_half ? v0 : v1;
+            const double got = __shfl_xor(give, 4);
+            const v2d pair = hi_half ? (v2d){got, v1} : (v2d){v0, got};
+            *(v2d *)(out + p_gather_index(i & ~4, hi_half ? j1 : j0)) = pair;
         }
 }
 
