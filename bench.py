@@ -115,7 +115,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)          # RCCL communicators are created lazily: fail here, not in the timed loop
+                torch.cuda.synchronize()
+            except Exception as exc:            # one double per rank and step: gloo over loopback carries it as well
+                print(f"[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); falling back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -188,7 +199,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: M8 (10 beta + 1 omega>1 class), 100 taxa x 10000 codons per GPU, "
                                    "random bushy tree, tree length %.2f subst/codon, 1%% gap codons" % case.tree_length,
                        "taxa": N_TAXA, "codons_per_gpu": N_SITES, "patterns_per_gpu": n_pat, "classes": K,
-                       "branches": n_branches, "sharding": f"patterns over {world} GPU(s)", "lnL": lnL},
+                       "branches": n_branches, "sharding": f"patterns over {world} GPU(s)",
+                       "collective": "none" if world == 1 else ("rccl" if backend == "nccl" else backend), "lnL": lnL},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "prune_kernel_nt1", "kernel_ms": kernel_ms,
