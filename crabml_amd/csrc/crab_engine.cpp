@@ -258,11 +258,10 @@ struct crab_engine : TreeProgram {
     // ---- device state ----
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
-    DevBuf<double> d_weights, d_teff, d_P, d_pi, d_props, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_eig_id, d_stack_e, d_e, d_beb_cols;
+    DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols;
     DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
     PinBuf<double> h_eig, h_small, h_out;
-    PinBuf<int32_t> h_int;
 
     EigPool eig_pool;
     int64_t eig_hits = 0, eig_misses = 0;
@@ -277,11 +276,11 @@ struct crab_engine : TreeProgram {
     {
         (void)hipSetDevice(device);
         eig_pool.release();
-        d_ops.release(); d_codes.release(); d_weights.release(); d_teff.release(); d_P.release();
-        d_pi.release(); d_props.release(); d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_eig_id.release(); d_stack_e.release(); d_e.release();
+        d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
+        d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
-        h_eig.release(); h_small.release(); h_out.release(); h_int.release();
+        h_eig.release(); h_small.release(); h_out.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (ev_k0) (void)hipEventDestroy(ev_k0);
@@ -834,20 +833,20 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             e->dev_ops.swap(progs);
         }
     }
-    const size_t n_small = (size_t)pl.M + NS + pl.K;
+    // the small per-call inputs travel in one copy: [t_eff M][pi NS][props K][eigensystem slot per matrix, int32 M]
+    const size_t n_small = (size_t)pl.M + NS + pl.K + ((size_t)pl.M + 1) / 2;
     e->h_small.ensure(n_small);
     double *hs = e->h_small.p;
     std::memcpy(hs, pl.t_eff.data(), pl.M * sizeof(double));
     for (int i = 0; i < NS; ++i) hs[pl.M + i] = i < n ? pi[i] : 0.0;
     for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
-    const size_t n_int = (size_t)pl.M;
-    e->h_int.ensure(n_int);
-    for (int m = 0; m < pl.M; ++m) e->h_int.p[m] = pool_slot[uniq_of[pl.eig_id[m]]];
+    int32_t *h_ids = reinterpret_cast<int32_t *>(hs + pl.M + NS + pl.K);
+    for (int m = 0; m < pl.M; ++m) h_ids[m] = pool_slot[uniq_of[pl.eig_id[m]]];
+    if (pl.M & 1) h_ids[pl.M] = 0;
 
-    e->d_teff.ensure(pl.M);
-    e->d_pi.ensure(NS);
-    e->d_props.ensure(pl.K);
-    e->d_eig_id.ensure(pl.M);
+    e->d_small.ensure(n_small);
+    double *d_teff = e->d_small.p, *d_pi = d_teff + pl.M, *d_props = d_pi + NS;
+    int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
     e->d_P.ensure((size_t)pl.M * P_ELEMS);
     const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
     const int grid = prune_grid_size(n_tiles * pl.K);
@@ -861,14 +860,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_lnL.ensure(G);
     if (pl.by_class) e->d_byclass.ensure((size_t)e->n_pat * pl.K + 1);
 
-    HIP_CHECK(hipMemcpyAsync(e->d_teff.p, hs, pl.M * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipMemcpyAsync(e->d_pi.p, hs + pl.M, NS * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipMemcpyAsync(e->d_props.p, hs + pl.M + NS, pl.K * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipMemcpyAsync(e->d_eig_id.p, e->h_int.p, pl.M * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_small.p, hs, n_small * sizeof(double), hipMemcpyHostToDevice, e->stream));
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
-    launch_build_p(pool.d, e->d_eig_id.p, e->d_teff.p, e->d_P.p, pl.M, n, true, e->stream);
+    launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, pl.M, n, true, e->stream);
 
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
@@ -878,7 +874,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.K = pl.K;
     pa.codes = e->d_codes.p;
     pa.n_pat_pad = e->n_pat_pad;
-    pa.pi_pad = e->d_pi.p;
+    pa.pi_pad = d_pi;
     pa.n_states = n;
     pa.stack = e->d_stack.p;
     pa.stack_e = e->d_stack_e.p;
@@ -902,7 +898,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         e->d_beb_w.ensure(G);
         e->d_beb_post.ensure((size_t)std::max<int64_t>(1, e->n_pat) * Kc);
         HIP_CHECK(hipMemcpyAsync(e->d_beb_w.p, pl.post_weights, G * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        launch_class_posteriors(e->d_f.p, e->d_e.p, G, Kc, e->n_pat, e->n_pat_pad, e->d_props.p, e->d_beb_w.p, e->d_beb_post.p, e->stream);
+        launch_class_posteriors(e->d_f.p, e->d_e.p, G, Kc, e->n_pat, e->n_pat_pad, d_props, e->d_beb_w.p, e->d_beb_post.p, e->stream);
         if (e->n_pat > 0)
             HIP_CHECK(hipMemcpyAsync(e->h_out.p + G, e->d_beb_post.p, (size_t)e->n_pat * Kc * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     } else if (pl.beb) {
@@ -959,7 +955,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         ma.f = e->d_f.p;
         ma.e = e->d_e.p;
         ma.weights = e->d_weights.p;
-        ma.props = e->d_props.p;
+        ma.props = d_props;
         ma.K = pl.K / G;
         ma.n_groups = G;
         ma.n_pat = e->n_pat;
