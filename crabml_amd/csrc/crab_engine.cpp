@@ -821,11 +821,53 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     // (the new entries are registered further down, while the device is busy)
     e->last_eigen_ms = now_ms() - t0;
 
+    // ---- transition matrices to build.  In a batch most of them repeat: a finite-difference stencil changes one branch
+    // length or one class per vector, so (eigensystem, t) pairs are built once and shared (at C2 a 203-vector gradient
+    // would otherwise build 28 GB of matrices; at C3 more than the card holds).  Single evaluations skip the search. ----
+    int M = pl.M;
+    std::vector<int32_t> mat_slot(M);      // eigensystem pool slot of matrix m
+    for (int m = 0; m < M; ++m) mat_slot[m] = pool_slot[uniq_of[pl.eig_id[m]]];
+    const std::vector<double> *t_eff = &pl.t_eff;
+    const std::vector<int32_t> *pidx = &pl.pidx;
+    std::vector<double> t_u;
+    std::vector<int32_t> slot_u, pidx_u;
+    if (pl.n_groups > 1 && M > 1) {
+        size_t cap = 64;
+        while (cap < (size_t)M * 2) cap <<= 1;
+        std::vector<int32_t> table(cap, -1), remap(M);
+        for (int m = 0; m < M; ++m) {
+            uint64_t tb;
+            std::memcpy(&tb, &pl.t_eff[m], 8);
+            size_t h = (size_t)mix64(tb, (uint64_t)mat_slot[m]) & (cap - 1);
+            for (;;) {
+                const int32_t u = table[h];
+                if (u < 0) {
+                    table[h] = (int32_t)t_u.size();
+                    remap[m] = (int32_t)t_u.size();
+                    t_u.push_back(pl.t_eff[m]);
+                    slot_u.push_back(mat_slot[m]);
+                    break;
+                }
+                if (slot_u[u] == mat_slot[m] && std::memcmp(&t_u[u], &pl.t_eff[m], 8) == 0) {
+                    remap[m] = u;
+                    break;
+                }
+                h = (h + 1) & (cap - 1);
+            }
+        }
+        pidx_u.resize(pl.pidx.size());
+        for (size_t i = 0; i < pl.pidx.size(); ++i) pidx_u[i] = remap[pl.pidx[i]];
+        M = (int)t_u.size();
+        mat_slot.swap(slot_u);
+        t_eff = &t_u;
+        pidx = &pidx_u;
+    }
+
     // ---- uploads ----
-    if (e->dev_ops.empty() || pl.pidx != e->dev_pidx) {   // the programs depend on the tree and on this table only
+    if (e->dev_ops.empty() || *pidx != e->dev_pidx) {   // the programs depend on the tree and on this table only
         std::vector<DevOp> progs;
-        resolve_programs(e, pl.K, pl.pidx, progs);
-        e->dev_pidx = pl.pidx;
+        resolve_programs(e, pl.K, *pidx, progs);
+        e->dev_pidx = *pidx;
         {
             e->d_ops.ensure(progs.size());
             HIP_CHECK(hipMemcpyAsync(e->d_ops.p, progs.data(), progs.size() * sizeof(DevOp), hipMemcpyHostToDevice, e->stream));
@@ -834,20 +876,20 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     }
     // the small per-call inputs travel in one copy: [t_eff M][pi NS][props K][eigensystem slot per matrix, int32 M]
-    const size_t n_small = (size_t)pl.M + NS + pl.K + ((size_t)pl.M + 1) / 2;
+    const size_t n_small = (size_t)M + NS + pl.K + ((size_t)M + 1) / 2;
     e->h_small.ensure(n_small);
     double *hs = e->h_small.p;
-    std::memcpy(hs, pl.t_eff.data(), pl.M * sizeof(double));
-    for (int i = 0; i < NS; ++i) hs[pl.M + i] = i < n ? pi[i] : 0.0;
-    for (int k = 0; k < pl.K; ++k) hs[pl.M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
-    int32_t *h_ids = reinterpret_cast<int32_t *>(hs + pl.M + NS + pl.K);
-    for (int m = 0; m < pl.M; ++m) h_ids[m] = pool_slot[uniq_of[pl.eig_id[m]]];
-    if (pl.M & 1) h_ids[pl.M] = 0;
+    std::memcpy(hs, t_eff->data(), M * sizeof(double));
+    for (int i = 0; i < NS; ++i) hs[M + i] = i < n ? pi[i] : 0.0;
+    for (int k = 0; k < pl.K; ++k) hs[M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
+    int32_t *h_ids = reinterpret_cast<int32_t *>(hs + M + NS + pl.K);
+    for (int m = 0; m < M; ++m) h_ids[m] = mat_slot[m];
+    if (M & 1) h_ids[M] = 0;
 
     e->d_small.ensure(n_small);
-    double *d_teff = e->d_small.p, *d_pi = d_teff + pl.M, *d_props = d_pi + NS;
+    double *d_teff = e->d_small.p, *d_pi = d_teff + M, *d_props = d_pi + NS;
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
-    e->d_P.ensure((size_t)pl.M * P_ELEMS);
+    e->d_P.ensure((size_t)M * P_ELEMS);
     const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
     const int grid = prune_grid_size(n_tiles * pl.K);
     e->d_stack.ensure(prune_stack_doubles(grid, e->max_depth));
@@ -864,7 +906,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
-    launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, pl.M, n, true, e->stream);
+    launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, M, n, true, e->stream);
 
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
@@ -998,9 +1040,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_device_ms = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev_k0, e->ev_k1));
     e->last_prune_ms = ms;
-    e->last_pidx = pl.pidx;
+    e->last_pidx = *pidx;
     e->last_K = pl.K;
-    e->last_M = pl.M;
+    e->last_M = M;
     e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
     e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
 
