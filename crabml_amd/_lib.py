@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcrabml_amd.so")
 
 CRAB_OK, CRAB_ERR_ARG, CRAB_ERR_NO_ROOT, CRAB_ERR_EIGEN, CRAB_ERR_DEVICE, CRAB_ERR_STATE = range(6)
 CRAB_FLAG_NO_CLAMP = 1
+CRAB_FLAG_BEB_PARTIAL, CRAB_FLAG_BEB_GIVEN_LNFX = 2, 4
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)

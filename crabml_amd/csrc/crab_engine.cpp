@@ -708,11 +708,13 @@ struct EvalPlan {
     bool by_class = false;
     bool clamp = true;
     struct Beb {                        // grid integration of site posteriors after the pruning pass (kernel 4)
+        enum Mode { WHOLE, PARTIAL, GIVEN };   // whole alignment here; or one pattern slice: its lnfX only / posteriors from the summed lnfX
+        Mode mode = WHOLE;
         int G = 0, n_mix = 0;
         const int32_t *cols = nullptr;  // [G][n_mix] class index of each mixture component
         const double *props = nullptr;  // [G][n_mix]
         double *post = nullptr;         // out [n_sites][n_mix]
-        double *lnfx = nullptr;         // out [G] or null
+        double *lnfx = nullptr;         // out [G] or null (in, with GIVEN)
         double *ln_fx = nullptr;        // out: ln f(X) = logsumexp_g lnfx[g]
     };
     const Beb *beb = nullptr;
@@ -972,22 +974,29 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         ba.post = e->d_beb_post.p;
         double *h_lnfx = e->h_out.p + G, *h_w = h_lnfx + bb.G, *h_post = h_w + bb.G;
         launch_beb_scale(ba, e->stream);
-        launch_beb_grid_lnf(ba, e->stream);
-        HIP_CHECK(hipMemcpyAsync(h_lnfx, e->d_beb_lnfx.p, bb.G * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIP_CHECK(hipStreamSynchronize(e->stream));
-        if (e->n_pat == 0)
-            for (int g = 0; g < bb.G; ++g) h_lnfx[g] = 0.0;
-        // ln f(X) = ln sum_g exp(lnfX_g) around the largest term (beb.py:609-611); posterior grid weights
-        double s2 = -std::numeric_limits<double>::infinity(), sum = 0.0;
-        for (int g = 0; g < bb.G; ++g) s2 = std::max(s2, h_lnfx[g]);
-        for (int g = 0; g < bb.G; ++g) sum += std::exp(h_lnfx[g] - s2);
-        const double ln_fx = std::log(sum) + s2;
-        for (int g = 0; g < bb.G; ++g) h_w[g] = std::exp(h_lnfx[g] - ln_fx);
-        HIP_CHECK(hipMemcpyAsync(e->d_beb_w.p, h_w, bb.G * sizeof(double), hipMemcpyHostToDevice, e->stream));
-        launch_beb_posteriors(ba, e->stream);
-        if (e->n_pat > 0)
-            HIP_CHECK(hipMemcpyAsync(h_post, e->d_beb_post.p, (size_t)e->n_pat * bb.n_mix * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        if (bb.lnfx) std::copy(h_lnfx, h_lnfx + bb.G, bb.lnfx);
+        if (bb.mode != EvalPlan::Beb::GIVEN) {
+            launch_beb_grid_lnf(ba, e->stream);
+            HIP_CHECK(hipMemcpyAsync(h_lnfx, e->d_beb_lnfx.p, bb.G * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+            if (e->n_pat == 0)
+                for (int g = 0; g < bb.G; ++g) h_lnfx[g] = 0.0;
+        } else {
+            std::copy(bb.lnfx, bb.lnfx + bb.G, h_lnfx);   // summed over all pattern slices by the caller
+        }
+        double ln_fx = 0.0;
+        if (bb.mode != EvalPlan::Beb::PARTIAL) {
+            // ln f(X) = ln sum_g exp(lnfX_g) around the largest term (beb.py:609-611); posterior grid weights
+            double s2 = -std::numeric_limits<double>::infinity(), sum = 0.0;
+            for (int g = 0; g < bb.G; ++g) s2 = std::max(s2, h_lnfx[g]);
+            for (int g = 0; g < bb.G; ++g) sum += std::exp(h_lnfx[g] - s2);
+            ln_fx = std::log(sum) + s2;
+            for (int g = 0; g < bb.G; ++g) h_w[g] = std::exp(h_lnfx[g] - ln_fx);
+            HIP_CHECK(hipMemcpyAsync(e->d_beb_w.p, h_w, bb.G * sizeof(double), hipMemcpyHostToDevice, e->stream));
+            launch_beb_posteriors(ba, e->stream);
+            if (e->n_pat > 0)
+                HIP_CHECK(hipMemcpyAsync(h_post, e->d_beb_post.p, (size_t)e->n_pat * bb.n_mix * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        }
+        if (bb.lnfx && bb.mode != EvalPlan::Beb::GIVEN) std::copy(h_lnfx, h_lnfx + bb.G, bb.lnfx);
         if (bb.ln_fx) *bb.ln_fx = ln_fx;
     } else if (pl.by_class) {
         launch_by_class(e->d_f.p, e->d_e.p, pl.K, e->n_pat, e->n_pat_pad, pl.clamp ? 1 : 0, e->d_byclass.p, e->stream);
@@ -1054,6 +1063,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             if (p < e->pat_begin || p >= e->pat_end) continue;
             std::memcpy(pl.post_out + (size_t)s * Kc, src + (size_t)(p - e->pat_begin) * Kc, Kc * sizeof(double));
         }
+    } else if (pl.beb && pl.beb->mode == EvalPlan::Beb::PARTIAL) {
+        // nothing per site: the caller sums the lnfX of all slices and comes back
     } else if (pl.beb) {
         const double *src = e->h_out.p + G + 2 * (size_t)pl.beb->G;
         const int nm = pl.beb->n_mix;
@@ -1311,18 +1322,20 @@ int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const do
 int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi, const double *branch_lengths, int G, int n_mix,
                        const int32_t *cols, const double *props, unsigned flags, double *posteriors, double *lnfx, double *ln_fx)
 {
-    (void)flags;
     if (!e) return CRAB_ERR_ARG;
     return guarded(e, [&] {
         check_ready(e);
-        if (K < 1 || !Q || !pi || !branch_lengths || G < 1 || !cols || !props || !posteriors)
+        const bool partial = flags & CRAB_FLAG_BEB_PARTIAL, given = flags & CRAB_FLAG_BEB_GIVEN_LNFX;
+        if (K < 1 || !Q || !pi || !branch_lengths || G < 1 || !cols || !props || (!posteriors && !partial) || (partial && given) ||
+            ((partial || given) && !lnfx))
             fail(CRAB_ERR_ARG, "crab_eval_beb_grid: bad arguments");
         if (K > NS - 1) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: at most 63 classes");
         if (n_mix < 1 || n_mix > BEB_MAX_MIX) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: n_mix must be in [1, 16]");
         for (size_t i = 0; i < (size_t)G * n_mix; ++i)
             if (cols[i] < 0 || cols[i] >= K) fail(CRAB_ERR_ARG, "crab_eval_beb_grid: class index out of range in the grid table");
-        if (e->pat_begin != 0 || e->pat_end != e->n_pat_total)
-            fail(CRAB_ERR_STATE, "crab_eval_beb_grid needs the whole alignment on one engine: f(X | grid point) is a product over all sites");
+        if (!partial && !given && (e->pat_begin != 0 || e->pat_end != e->n_pat_total))
+            fail(CRAB_ERR_STATE, "crab_eval_beb_grid needs the whole alignment on one engine (f(X | grid point) is a product over all "
+                                 "sites), or the two-call protocol of CRAB_FLAG_BEB_PARTIAL / CRAB_FLAG_BEB_GIVEN_LNFX");
         EvalPlan pl;
         plan_site_classes(e, pl, K, Q, branch_lengths);
         EvalPlan::Beb bb;
@@ -1333,6 +1346,7 @@ int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi,
         bb.post = posteriors;
         bb.lnfx = lnfx;
         bb.ln_fx = ln_fx;
+        bb.mode = partial ? EvalPlan::Beb::PARTIAL : (given ? EvalPlan::Beb::GIVEN : EvalPlan::Beb::WHOLE);
         pl.beb = &bb;
         run_plan(e, pl, pi, nullptr, nullptr, nullptr);
     });

@@ -143,3 +143,27 @@ def map_genes(fn, genes, workers: int = 8, make_engine=None):
             close = getattr(e, "close", None)
             if close:
                 close()
+
+
+def sharded_beb_grid(engine, Q, pi, branch_lengths, cols, props, group=None, device=None):
+    """BEB grid posteriors with the site patterns sharded over ranks: f(X | grid point) is a product over all sites, so
+    the slices' per-grid-point log-likelihoods are summed across ranks (one all-gather of G doubles, added in rank
+    order so that every rank holds the same bits) before each rank integrates the posteriors of its own sites.
+    Returns (posteriors [n_sites, n_mix] with NaN rows for other ranks' sites, ln f(X))."""
+    import torch
+    import torch.distributed as dist
+    _, part, _ = engine.beb_grid(Q, pi, branch_lengths, cols, props, partial=True)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        ws = dist.get_world_size(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        mine = torch.from_numpy(part).to(device)
+        parts = [torch.empty_like(mine) for _ in range(ws)]
+        dist.all_gather(parts, mine, group=group)
+        total = np.zeros_like(part)
+        for p_ in parts:
+            total = total + p_.cpu().numpy()
+    else:
+        total = part
+    post, _, ln_fx = engine.beb_grid(Q, pi, branch_lengths, cols, props, lnfx=total)
+    return post, ln_fx

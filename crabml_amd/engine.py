@@ -150,10 +150,12 @@ class Engine:
                                                           L.CRAB_FLAG_NO_CLAMP if no_clamp else 0, out.ctypes.data_as(L.dp)))
         return out
 
-    def beb_grid(self, Q, pi, branch_lengths, cols, props):
+    def beb_grid(self, Q, pi, branch_lengths, cols, props, partial=False, lnfx=None):
         """Site posteriors integrated over a parameter grid (analysis/beb.py:575-661 on the device).
         Q: [K, n, n]; cols int [G, n_mix] and props [G, n_mix] describe each grid point's mixture.
-        Returns (posteriors [n_sites, n_mix], lnfX per grid point [G], ln f(X))."""
+        Returns (posteriors [n_sites, n_mix], lnfX per grid point [G], ln f(X)).
+        Over pattern slices (one engine per GPU): ``partial=True`` returns (None, this slice's lnfX, 0.0); add the
+        slices' lnfX vectors and pass the sum as ``lnfx=`` to get the posteriors of this engine's sites."""
         Q_, Qp = self._q_stack(Q)
         pi_, pp = self._pi(pi)
         bl, blp = self._bl(branch_lengths)
@@ -162,13 +164,25 @@ class Engine:
         if cols_.ndim != 2 or props_.shape != cols_.shape:
             raise ValueError("cols and props must both have shape (G, n_mix)")
         G, n_mix = cols_.shape
-        post = np.full((self.n_sites, n_mix), np.nan)
-        lnfx = np.empty(G)
+        flags = 0
+        if partial:
+            flags, post = L.CRAB_FLAG_BEB_PARTIAL, None
+            lnfx_ = np.empty(G)
+        else:
+            post = np.full((self.n_sites, n_mix), np.nan)
+            if lnfx is None:
+                lnfx_ = np.empty(G)
+            else:
+                flags = L.CRAB_FLAG_BEB_GIVEN_LNFX
+                lnfx_ = np.ascontiguousarray(lnfx, dtype=np.float64).copy()
+                if lnfx_.shape != (G,):
+                    raise ValueError(f"lnfx must have one entry per grid point ({G})")
         ln_fx = C.c_double()
         self._check(self._lib.crab_eval_beb_grid(self._h, Q_.shape[0], Qp, pp, blp, G, n_mix, cols_.ctypes.data_as(L.ip),
-                                                 props_.ctypes.data_as(L.dp), 0, post.ctypes.data_as(L.dp),
-                                                 lnfx.ctypes.data_as(L.dp), C.byref(ln_fx)))
-        return post, lnfx, ln_fx.value
+                                                 props_.ctypes.data_as(L.dp), flags,
+                                                 post.ctypes.data_as(L.dp) if post is not None else None,
+                                                 lnfx_.ctypes.data_as(L.dp), C.byref(ln_fx)))
+        return post, lnfx_, ln_fx.value
 
     def branch_site(self, Q3, qfactor_back, qfactor_fore, omega0, omega2, site_class_freqs, pi, branch_lengths, labels,
                     return_sites=False):

@@ -54,6 +54,13 @@ typedef enum {
 #define CRAB_FLAG_NO_CLAMP 1u   /* drop the reference's max(f, 1e-300) clamps (likelihood.rs:161,332,356,450):
                                    exact log-likelihoods on trees long enough to underflow fp64 */
 
+/* crab_eval_beb_grid over pattern slices (multi-GPU): f(X | grid point) is a product over all sites, so each rank first
+ * calls with CRAB_FLAG_BEB_PARTIAL (lnfx receives this slice's sum_p w_p ln f_p(g); posteriors may be NULL), the ranks
+ * add their lnfx vectors (one all-reduce of G doubles), and each calls again with CRAB_FLAG_BEB_GIVEN_LNFX (lnfx is now
+ * input) to get the posteriors of its own sites. */
+#define CRAB_FLAG_BEB_PARTIAL 2u
+#define CRAB_FLAG_BEB_GIVEN_LNFX 4u
+
 /* ---- lifetime ------------------------------------------------------------ */
 /* device = HIP device ordinal (one engine per process/GPU is the intended use). */
 int crab_create(int device, crab_engine **out);

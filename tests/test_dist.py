@@ -134,3 +134,49 @@ def test_two_rank_gloo_gather_of_the_site_by_class_table():
         out = mgr.dict()
         mp.spawn(_table_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         assert all(out[r] for r in range(world))
+
+
+def _beb_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crabml_amd import beb
+        from crabml_amd.dist import sharded_beb_grid
+        from oracle import beb as obeb
+        c = load_case("lysozyme_m2a_beb")
+        cols, props = beb.paml_grid_m2a()
+        pick = np.arange(0, 10000, 53)
+        cols, props = cols[pick], props[pick]
+        table = c["site_log_liks"]
+        mine = np.arange(table.shape[0]) % world == rank          # this rank's sites
+
+        class SliceEngine:   # the two-call protocol of Engine.beb_grid, with the oracle standing in for the GPU
+            def beb_grid(self, Q, pi, bl, cols_, props_, partial=False, lnfx=None):
+                if partial:
+                    return None, obeb.site_posteriors(table[mine], cols_, props_)[1], 0.0
+                F = obeb.scale_table(table)
+                fx = np.log(np.exp(lnfx - lnfx.max()).sum()) + lnfx.max()
+                gw = np.exp(lnfx - fx)
+                post = np.full((table.shape[0], cols_.shape[1]), np.nan)
+                terms = props_[None, :, :] * F[:, cols_]                       # [S, G, n_mix]
+                post[mine] = ((terms / terms.sum(axis=2, keepdims=True)) * gw[None, :, None]).sum(axis=1)[mine]
+                return post, lnfx, fx
+
+        post, ln_fx = sharded_beb_grid(SliceEngine(), None, None, None, cols, props)
+        whole, _, whole_fx = obeb.site_posteriors(table, cols, props)
+        out[rank] = (bool(np.allclose(post[mine], whole[mine], rtol=1e-11, atol=1e-300)), bool(np.isnan(post[~mine]).all()),
+                     abs(ln_fx - whole_fx) < 1e-10, float(ln_fx))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_beb_grid_over_pattern_slices():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_beb_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert all(r[0] and r[1] and r[2] for r in res)
+    assert res[0][3] == res[1][3]          # rank-ordered sum: the same ln f(X) bits on every rank

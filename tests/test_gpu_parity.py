@@ -922,3 +922,36 @@ def test_beb_adaptive_grid_accumulation_against_the_reference(gpu_engine_cls):
     strict = obeb.site_posteriors_weighted(tables, c["grid_proportions"], c["weights"])   # the device's own tables through the oracle
     assert np.abs(post[big] / strict[big] - 1.0).max() <= 1e-9 and np.abs(post - strict).max() <= 1e-12
     np.testing.assert_allclose(post.sum(axis=1), c["weights"].sum(), atol=1e-12)
+
+
+def test_beb_grid_over_pattern_slices_equals_the_whole(gpu_engine_cls):
+    """The multi-GPU form of the BEB integration: three pattern slices, their lnfX vectors added, posteriors of each
+    slice's own sites from the sum -- together they must tile the whole-alignment result."""
+    from crabml_amd import beb
+    from crabml_amd.dist import sharded_beb_grid
+    c = load_case("lysozyme_m2a_beb")
+    cols, props = beb.paml_grid_m2a()
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        whole, lnfx, ln_fx = eng.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props)
+        n_pat = eng.n_patterns_total
+        alone, ln_alone = sharded_beb_grid(eng, c["Q"], c["pi"], c["branch_lengths"], cols, props)   # world size 1: same protocol
+    edges = [0, 37, 90, n_pat]
+    engines = [_engine(gpu_engine_cls, c["parent"], c["sequences"], pattern_begin=a, pattern_end=b) for a, b in zip(edges[:-1], edges[1:])]
+    try:
+        parts = [e.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props, partial=True)[1] for e in engines]
+        total = parts[0] + parts[1] + parts[2]
+        tiled = np.full_like(whole, np.nan)
+        for e in engines:
+            post, _, lf = e.beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props, lnfx=total)
+            have = ~np.isnan(post[:, 0])
+            assert not (have & ~np.isnan(tiled[:, 0])).any()
+            tiled[have] = post[have]
+            assert abs(lf - ln_fx) < 1e-9
+        with pytest.raises(ValueError, match="whole alignment"):
+            engines[0].beb_grid(c["Q"], c["pi"], c["branch_lengths"], cols, props)
+    finally:
+        for e in engines:
+            e.close()
+    np.testing.assert_allclose(total, lnfx, rtol=1e-12)
+    assert not np.isnan(tiled).any() and np.abs(tiled - whole).max() <= 1e-12
+    assert np.abs(alone - whole).max() <= 1e-13 and abs(ln_alone - ln_fx) < 1e-10
