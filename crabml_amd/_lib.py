@@ -50,6 +50,7 @@ SIGNATURES = {
     "crab_model_a_quantities": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]),
     "crab_last_timing": (C.c_int, [vp, dp, dp, dp]),
     "crab_last_work": (C.c_int, [vp, lp, lp]),
+    "crab_eig_pool_stats": (C.c_int, [vp, lp, lp, lp]),
     "crab_export_transition_matrices": (C.c_int, [vp, C.c_int, dp]),
     "crab_matrix_exponential": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_double, dp]),
     "crab_build_codon_q_matrix": (C.c_int, [C.c_double, C.c_double, dp, C.c_int, C.c_double, dp]),

@@ -1456,6 +1456,19 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
     });
 }
 
+int crab_eig_pool_stats(const crab_engine *e, int64_t *hits, int64_t *misses, int64_t *resident)
+{
+    if (!e) return CRAB_ERR_ARG;
+    if (hits) *hits = e->eig_hits;
+    if (misses) *misses = e->eig_misses;
+    if (resident) {
+        int64_t n = 0;
+        for (const auto &en : e->eig_pool.slots) n += en.used ? 1 : 0;
+        *resident = n;
+    }
+    return CRAB_OK;
+}
+
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)
 {
     if (!e) return CRAB_ERR_ARG;

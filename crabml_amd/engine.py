@@ -302,6 +302,12 @@ class Engine:
         self._check(self._lib.crab_export_transition_matrices(self._h, int(k), out.ctypes.data_as(L.dp)))
         return out
 
+    def eig_pool_stats(self):
+        """(hits, misses, resident entries) of this engine's eigensystem pool since creation."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._lib.crab_eig_pool_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def last_work(self):
         """(dense MFMA updates, gathered leaf updates) of the last evaluation, in pattern x branch x class units."""
         a, b = C.c_int64(), C.c_int64()

@@ -183,6 +183,11 @@ int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kern
  * (pattern x branch x class) updates executed as MFMA products, and of leaf-edge updates done as gathers. */
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates);
 
+/* Eigensystem pool of this engine since creation: distinct decompositions found resident (hits), decomposed anew
+ * (misses), and entries resident now.  Replaces nothing in the reference (it decomposes every matrix on every call,
+ * lib.rs:163-169,387-393); lets callers and tests see that a parameter change decomposed only what it had to. */
+int crab_eig_pool_stats(const crab_engine *e, int64_t *hits, int64_t *misses, int64_t *resident);
+
 /* Copies out the transition matrices the last crab_eval_* built on the device for class k:
  * P_out[v][i][j] = P(branch above node v)[i][j], shape [n_nodes][n][n].  Lets a caller (and the parity
  * tests) check kernel 1 and kernel 2 separately.  Replaces nothing in the reference: its P matrices

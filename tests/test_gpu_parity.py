@@ -955,3 +955,39 @@ def test_beb_grid_over_pattern_slices_equals_the_whole(gpu_engine_cls):
     np.testing.assert_allclose(total, lnfx, rtol=1e-12)
     assert not np.isnan(tiled).any() and np.abs(tiled - whole).max() <= 1e-12
     assert np.abs(alone - whole).max() <= 1e-13 and abs(ln_alone - ln_fx) < 1e-10
+
+
+def test_parameter_changes_decompose_only_what_they_must(gpu_engine_cls):
+    """The eigensystem pool is keyed by (kappa, omega, pi) with every normalisation folded into the branch lengths:
+    repeating a point, moving a branch length or moving a class proportion decomposes nothing; moving one omega
+    decomposes one matrix; moving kappa decomposes all K."""
+    c = load_case("lysozyme_m8")
+    ka, om, pr, pi, bl = float(c["kappa"]), c["omegas"], c["proportions"], c["pi"], c["branch_lengths"]
+    K = len(om)
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        def misses(fn):
+            before = eng.eig_pool_stats()[1]
+            fn()
+            return eng.eig_pool_stats()[1] - before
+        assert misses(lambda: eng.codon_site_classes(ka, om, pr, pi, bl)) == K
+        assert misses(lambda: eng.codon_site_classes(ka, om, pr, pi, bl)) == 0
+        bl2 = bl.copy(); bl2[3] *= 1.001
+        assert misses(lambda: eng.codon_site_classes(ka, om, pr, pi, bl2)) == 0
+        pr2 = pr.copy(); pr2[:-1] *= 0.95 / pr[:-1].sum(); pr2[-1] = 0.05
+        a = eng.codon_site_classes(ka, om, pr, pi, bl)
+        assert misses(lambda: eng.codon_site_classes(ka, om, pr2, pi, bl)) == 0       # the shared scale changed: t / scale, same eigensystems
+        assert eng.codon_site_classes(ka, om, pr2, pi, bl) != a
+        om2 = om.copy(); om2[-1] *= 1.01
+        assert misses(lambda: eng.codon_site_classes(ka, om2, pr, pi, bl)) == 1
+        assert misses(lambda: eng.codon_site_classes(ka * 1.01, om, pr, pi, bl)) == K
+        # a whole gradient stencil in one call: 1 + n_branches + K + 1 vectors, K + K + 1 ... new matrices only for the omega and kappa rows
+        B = 1 + 4 + 2
+        kas = np.full(B, ka); kas[6] *= 1.02
+        oms = np.repeat(om[None], B, 0); oms[5, 0] *= 1.02
+        bls = np.repeat(bl[None], B, 0); bls[np.arange(1, 5), np.arange(4)] *= 1.001
+        assert misses(lambda: eng.codon_site_classes(kas, oms, np.repeat(pr[None], B, 0), pi, bls)) == 1 + K
+        hits, miss, resident = eng.eig_pool_stats()
+        assert resident == miss and hits > 0
+        # matrices passed by value share the pool, keyed by their contents
+        assert misses(lambda: eng.site_classes(c["Q"], pr, pi, bl)) == K
+        assert misses(lambda: eng.site_classes(c["Q"], pr, pi, bl2)) == 0
