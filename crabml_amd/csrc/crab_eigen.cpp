@@ -213,7 +213,7 @@ namespace {
 class Pool {
     struct Job {   // lives on its caller's stack; every field is guarded by m_
         const std::function<void(int)> *fn;
-        int n, next = 0, done = 0;
+        int n, chunk = 1, next = 0, done = 0;
     };
 
   public:
@@ -249,6 +249,7 @@ class Pool {
         Job job;
         job.fn = &fn;
         job.n = n;
+        job.chunk = std::max(1, n / (8 * n_threads_));   // 11 decompositions: one each; 700 hashes: blocks of 5
         std::unique_lock<std::mutex> lk(m_);
         jobs_.push_back(&job);
         lk.unlock();
@@ -265,13 +266,16 @@ class Pool {
     void drain(Job *job, std::unique_lock<std::mutex> &lk)
     {
         while (job->next < job->n) {
-            const int i = job->next++;
+            const int i0 = job->next;
+            const int cnt = std::min(job->chunk, job->n - i0);   // short iterations are handed out in blocks
+            job->next += cnt;
             if (job->next == job->n) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), job));   // nothing left to hand out
             const std::function<void(int)> *fn = job->fn;
             lk.unlock();
-            (*fn)(i);
+            for (int i = i0; i < i0 + cnt; ++i) (*fn)(i);
             lk.lock();
-            if (++job->done == job->n) {
+            job->done += cnt;
+            if (job->done == job->n) {
                 done_cv_.notify_all();
                 return;
             }

@@ -756,22 +756,41 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     } else {
         parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
-        std::unordered_map<uint64_t, std::vector<int>> seen;
-        for (int i = 0; i < pl.n_eig; ++i) {
-            const double *Qi = Q + (size_t)i * n * n;
-            auto &cands = seen[qhash[i]];
-            int slot = -1;
-            for (int u : cands)
-                if (std::memcmp(Q + (size_t)uniq_src[u] * n * n, Qi, sizeof(double) * n * n) == 0) {
-                    slot = u;
-                    break;
+        // group by hash, then confirm every presumed duplicate against its representative byte for byte, in parallel
+        // (a batch of B vectors repeats almost all of its B x K matrices); a hash collision falls back to the exact search
+        auto group = [&](bool exact) {
+            uniq_src.clear();
+            std::unordered_map<uint64_t, std::vector<int>> seen;
+            for (int i = 0; i < pl.n_eig; ++i) {
+                const double *Qi = Q + (size_t)i * n * n;
+                auto &cands = seen[qhash[i]];
+                int slot = -1;
+                for (int u : cands)
+                    if (!exact || std::memcmp(Q + (size_t)uniq_src[u] * n * n, Qi, sizeof(double) * n * n) == 0) {
+                        slot = u;
+                        break;
+                    }
+                if (slot < 0) {
+                    slot = (int)uniq_src.size();
+                    uniq_src.push_back(i);
+                    cands.push_back(slot);
                 }
-            if (slot < 0) {
-                slot = (int)uniq_src.size();
-                uniq_src.push_back(i);
-                cands.push_back(slot);
+                uniq_of[i] = slot;
             }
-            uniq_of[i] = slot;
+        };
+        group(false);
+        const int dupes = pl.n_eig - (int)uniq_src.size();
+        if (dupes > 0) {
+            std::atomic<int> collisions{0};
+            auto check = [&](int i) {
+                const int rep = uniq_src[uniq_of[i]];
+                if (rep != i && std::memcmp(Q + (size_t)rep * n * n, Q + (size_t)i * n * n, sizeof(double) * n * n) != 0) ++collisions;
+            };
+            if (dupes < 64)
+                for (int i = 0; i < pl.n_eig; ++i) check(i);
+            else
+                parallel_for(pl.n_eig, check);
+            if (collisions.load() != 0) group(true);
         }
     }
     const int n_uniq = (int)uniq_src.size();
