@@ -755,7 +755,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             uniq_src.push_back(i);
         }
     } else {
-        parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
+        if ((size_t)pl.n_eig * n * n * sizeof(double) < (1u << 20))   // a few matrices: cheaper than waking the pool (measured)
+            for (int i = 0; i < pl.n_eig; ++i) qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih);
+        else
+            parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
         // group by hash, then confirm every presumed duplicate against its representative byte for byte, in parallel
         // (a batch of B vectors repeats almost all of its B x K matrices); a hash collision falls back to the exact search
         auto group = [&](bool exact) {
