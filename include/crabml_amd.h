@@ -111,7 +111,8 @@ int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const do
  * every grid point (:589-607), ln f(X) (:609-611) and the class posteriors of every site (:614-659; in the reference
  * pure-Python loops over n_sites x 10 000 grid points, twice).  Grid point g mixes n_mix (<= 16) of the K classes:
  * f_s(g) = sum_c props[g*n_mix + c] * f_{cols[g*n_mix + c], s}.  posteriors: [n_sites][n_mix]; lnfx: optional [G];
- * ln_fx: optional scalar.  Needs the whole alignment on this engine (no pattern slice). */
+ * ln_fx: optional scalar.  With flags = 0 the engine must hold the whole alignment; engines holding pattern slices use
+ * the two-call protocol of CRAB_FLAG_BEB_PARTIAL / CRAB_FLAG_BEB_GIVEN_LNFX (above). */
 int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi, const double *branch_lengths, int G,
                        int n_mix, const int32_t *cols, const double *props, unsigned flags, double *posteriors,
                        double *lnfx, double *ln_fx);
