@@ -132,9 +132,10 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // of v_mfma_f64_4x4x4_4b_f64.  Since these registers are invisible to the compiler, every asm that loads into them
 // is followed by an explicit s_waitcnt before the first use.
 // With NT = 1 (256 registers, two waves per SIMD) there is room for more tiles: G receives the columns of the next
-// leaf edge while products run (the gather's L2 round trip hides under MFMA work), and S0, S1 hold the top of the
-// stack of saved sibling products, so that on trees of Sethi-Ullman depth <= 2 no conditional likelihood ever
-// leaves the register file; deeper slots (and every slot with NT = 2) go to the global-memory stack.
+// leaf edge while products run (the gather's L2 round trip hides under MFMA work), and S0, S1 hold stack slots 0 and 1
+// of the saved sibling products -- the host numbers the slots by how often the tree writes them, so these are the two
+// busiest frame depths; on trees of Sethi-Ullman depth <= 2 no conditional likelihood ever leaves the register
+// file.  The other slots (and every slot with NT = 2) go to the global-memory stack.
 constexpr int N_XCD = 8;  // the launch grid is a multiple of this
 
 template <int NT>
