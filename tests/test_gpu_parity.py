@@ -991,3 +991,44 @@ def test_parameter_changes_decompose_only_what_they_must(gpu_engine_cls):
         # matrices passed by value share the pool, keyed by their contents
         assert misses(lambda: eng.site_classes(c["Q"], pr, pi, bl)) == K
         assert misses(lambda: eng.site_classes(c["Q"], pr, pi, bl2)) == 0
+
+
+def test_random_batches_equal_single_evaluations_bit_for_bit(gpu_engine_cls):
+    """Batches share identical transition matrices between their vectors: whatever the pattern of repeats (identical
+    vectors, one branch moved, many branches moved, a class or kappa moved), every element must equal the evaluation of
+    its vector alone, bit for bit, for rate matrices passed by value and for parameters."""
+    from crabml_amd import synth
+    rng = np.random.default_rng(314 + int(os.environ.get("CRAB_SWEEP_SEED", "0")))
+    case = synth.make_case("M8", 14, 150, seed=8)
+    K, nn = len(case.proportions), case.n_nodes
+    om, pr = case.class_omegas, np.asarray(case.proportions)
+    with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
+        for B in (2, 5, 17):
+            bl = np.repeat(case.branch_lengths[None], B, 0)
+            ka = np.full(B, case.kappa)
+            oms, prs = np.repeat(om[None], B, 0), np.repeat(pr[None], B, 0)
+            Q = np.repeat(case.Q[None], B, 0)
+            for b in range(1, B):
+                kind = rng.integers(0, 6)
+                if kind == 0:
+                    pass                                                    # identical to the base vector
+                elif kind == 1:
+                    bl[b, rng.integers(0, nn - 1)] *= 1.0 + 1e-6
+                elif kind == 2:
+                    bl[b, rng.random(nn) < 0.5] *= 1.0 + 1e-3
+                elif kind == 3:
+                    ka[b] *= 1.0 + 1e-4
+                    Q[b] = Q[b] * (1.0 + 1e-4)
+                elif kind == 4:
+                    k = rng.integers(0, K)
+                    oms[b, k] *= 1.0 + 1e-4
+                    Q[b, k] = Q[b, k] * (1.0 + 1e-4)
+                else:
+                    bl[b] = bl[rng.integers(0, b)]                          # repeats an earlier vector's branch lengths
+            got = eng.codon_site_classes(ka, oms, prs, case.pi, bl)
+            want = [eng.codon_site_classes(ka[b], oms[b], prs[b], case.pi, bl[b]) for b in range(B)]
+            assert list(got) == want, f"parameters, B={B}"
+            got_q = eng.site_classes_batch(Q, prs, case.pi, bl)
+            want_q = [eng.site_classes(Q[b], prs[b], case.pi, bl[b]) for b in range(B)]
+            assert list(got_q) == want_q, f"matrices by value, B={B}"
+            assert np.isfinite(got).all() and np.isfinite(got_q).all()
