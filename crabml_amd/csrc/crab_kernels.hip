@@ -357,8 +357,13 @@ __device__ __forceinline__ void gemm_first_half(unsigned lds_addr)
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 - Q) : "memory");
     }
     constexpr int A = R_AV + (b * 4 + Q) * 4;
-    r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp), sp == 0>();
-    if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp), sp == 0>();
+#ifdef CRAB_SKIP15_EMU   // timing emulation only (scripts/micro/gemm_tile_rate.hip): what a 15 x 15 block product would issue
+    if constexpr (ic * 4 + Q != 15)
+#endif
+    {
+        r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp), sp == 0>();
+        if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp), sp == 0>();
+    }
     if constexpr (Q + 1 < 4) gemm_first_half<NT, X, Y, GI, Q + 1>(lds_addr);
 }
 template <int NT, int X, int Y, int GI, int Q>
@@ -367,8 +372,13 @@ __device__ __forceinline__ void gemm_second_half()
     constexpr int R_AV = Plan<NT>::AV;
     constexpr int sp = GI >> 2, ic = GI & 3, b = GI & 1;
     constexpr int A = R_AV + (b * 4 + Q) * 4 + 2;
-    r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp + 1), false>();
-    if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp + 1), false>();
+#ifdef CRAB_SKIP15_EMU
+    if constexpr (ic * 4 + Q != 15 && 2 * sp + 1 != 15)
+#endif
+    {
+        r_mfma<Y + 2 * (ic * 4 + Q), A, X + 2 * (2 * sp + 1), false>();
+        if constexpr (NT == 2) r_mfma<Y + 32 + 2 * (ic * 4 + Q), A, X + 32 + 2 * (2 * sp + 1), false>();
+    }
     if constexpr (Q + 1 < 4) gemm_second_half<NT, X, Y, GI, Q + 1>();
 }
 // Vector-memory traffic that rides inside a product, one instruction every second group (= 16*NT MFMAs), so that the

@@ -15,6 +15,40 @@ struct NoRide {
     __device__ __forceinline__ void after() const {}
 };
 
+#ifdef CRAB_SKIP15_EMU
+// What the border of a 60 + 1 split would add per product (timing only): 16 LDS reads of row/column 60 through the
+// A ring, 16 + 15 fp64 multiply-adds per pattern group, and the cross-lane sum and broadcast of state 60.
+template <int D, int A, int B>
+__device__ __forceinline__ void r_fma64()
+{
+    asm volatile("v_fma_f64 v[%0:%1], v[%2:%3], v[%4:%5], v[%0:%1]" ::"n"(D), "n"(D + 1), "n"(A), "n"(A + 1), "n"(B), "n"(B + 1));
+}
+template <int X, int Y, int... I>
+__device__ __forceinline__ void border_fma(std::integer_sequence<int, I...>)
+{
+    constexpr int AV = Plan<2>::AV;
+    (r_fma64<Y + 30, AV + 2 * (I & 15), X + 2 * I>(), ...);
+    (r_fma64<Y + 2 * (I % 15), AV + 2 * (I & 15), X + 30>(), ...);
+}
+template <int NT, int X, int Y>
+__device__ __forceinline__ void border_emu(unsigned lds_a, double seed)
+{
+    constexpr int AV = Plan<2>::AV;
+    for (int q = 0; q < 2; ++q) {
+        r_lds_read128<AV + 0, 0>(lds_a); r_lds_read128<AV + 4, 256>(lds_a); r_lds_read128<AV + 8, 512>(lds_a); r_lds_read128<AV + 12, 768>(lds_a);
+        r_lds_read128<AV + 16, 1024>(lds_a); r_lds_read128<AV + 20, 1280>(lds_a); r_lds_read128<AV + 24, 1536>(lds_a); r_lds_read128<AV + 28, 1792>(lds_a);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    border_fma<X, Y>(std::make_integer_sequence<int, 16>{});
+    if constexpr (NT == 2) border_fma<X + 32, Y + 32>(std::make_integer_sequence<int, 16>{});
+    double s = 0.0;
+    r_fma_into<Y + 30>(s, seed);
+    auto a = __builtin_amdgcn_permlane16_swap(__double2hiint(s), __double2loint(s), false, false);
+    auto b2 = __builtin_amdgcn_permlane32_swap((int)a[0], (int)a[1], false, false);
+    if (b2[0] == 0x7fffffff) asm volatile("s_nop 0");   // keep the swaps alive
+}
+#endif
+
 template <int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(double *out, const double *img, int reps, unsigned long long *clk)
 {
@@ -33,7 +67,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void k(do
     if (MODE == 0) {
         for (int r = 0; r < reps; r += 2) {   // ping-pong, like the walk
             gemm_tile<NT, X, Y>(lds_a, NoRide{});
+#ifdef CRAB_SKIP15_EMU
+            border_emu<NT, X, Y>(lds_a, seed);
+#endif
             gemm_tile<NT, Y, X>(lds_a, NoRide{});
+#ifdef CRAB_SKIP15_EMU
+            border_emu<NT, Y, X>(lds_a, seed);
+#endif
         }
     } else {
         // MODE 1: the kernel's Ride hooks with nothing to do; MODE 2: with the LDS-DMA of an image riding along
