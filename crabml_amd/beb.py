@@ -79,3 +79,126 @@ def site_posteriors_over_grid(engine, class_parameters, weights, pi, branch_leng
         part = engine.codon_class_posteriors(ka, om, pr, np.asarray(weights[lo:lo + batch], dtype=np.float64), pi, branch_lengths)
         total = part if total is None else total + part
     return total
+
+
+# ---- the adaptive grid: Hessian at the MLE, principal axes, weighted grid (beb.py:201-387, 733-796) ----------------
+def in_bounds(names, x) -> bool:
+    """BEBCalculator._check_bounds (beb.py:201-232) for the parameter vector x in the order of ``names``; parameters
+    that are not integrated over are inside their bounds by assumption (they sit at the MLE)."""
+    for name, v in zip(names, x):
+        if name == "kappa" and v <= 0:
+            return False
+        if name.startswith("p") and not name.endswith("beta") and (v < 0 or v > 1):
+            return False
+        if name in ("p_beta", "q_beta") and v <= 0:
+            return False
+        if name.startswith("omega") and v < 0:
+            return False
+    return True
+
+
+def hessian_points(x, h: float = 1e-5):
+    """The distinct points of the reference's stencil (beb.py:275-294): x, x + h e_i, and (x + h e_i) + h e_j for
+    i <= j -- 1 + n + n(n + 1)/2 of them where the reference makes 4 evaluations per (i, j), 2 n (n + 1) in all.
+    Returns (points [m, n], single [n], pair [n, n]): row indices of x + h e_i and of x + h e_i + h e_j (j >= i)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    eye = np.eye(n) * h
+    pts = [x.copy()]
+    single = np.zeros(n, dtype=np.int64)
+    pair = np.full((n, n), -1, dtype=np.int64)
+    for i in range(n):
+        single[i] = len(pts)
+        pts.append(x + eye[i])
+    for i in range(n):
+        for j in range(i, n):
+            pair[i, j] = len(pts)
+            pts.append(x + eye[i] + eye[j])
+    return np.asarray(pts), single, pair
+
+
+def hessian_from_values(neg_lnl, single, pair, h: float = 1e-5):
+    """beb.py:287-294 on the values at hessian_points: H_ij = (f_11 - f_10 - f_01 + f_00) / (h h), symmetric."""
+    n = len(single)
+    H = np.zeros((n, n))
+    with np.errstate(invalid="ignore"):
+        for i in range(n):
+            for j in range(i, n):
+                H[i, j] = H[j, i] = (neg_lnl[pair[i, j]] - neg_lnl[single[i]] - neg_lnl[single[j]] + neg_lnl[0]) / (h * h)
+    return H
+
+
+def _class_parameters(model_class, mle_params, names, x, pi):
+    model = model_class(**dict(mle_params, **dict(zip(names, map(float, x)))), pi=pi)
+    props, omegas = model.get_site_classes()
+    return float(model.kappa), np.asarray(omegas, dtype=np.float64), np.asarray(props, dtype=np.float64)
+
+
+def negative_log_likelihoods(engine, model_class, mle_params, names, points, pi, branch_lengths):
+    """``neg_log_likelihood`` of beb.py:247-263 at many parameter vectors in ONE call through the C ABI
+    (crab_eval_codon_site_classes with B = number of in-bounds points); out-of-bounds points are +inf as there."""
+    out = np.full(len(points), np.inf)
+    ok = [i for i, x in enumerate(points) if in_bounds(names, x)]
+    if ok:
+        cls = [_class_parameters(model_class, mle_params, names, points[i], pi) for i in ok]
+        out[ok] = -engine.codon_site_classes(np.array([c[0] for c in cls]), np.array([c[1] for c in cls]),
+                                             np.array([c[2] for c in cls]), pi,
+                                             np.broadcast_to(np.asarray(branch_lengths, dtype=np.float64), (len(ok), len(branch_lengths))))
+    return out
+
+
+def hessian(engine, model_class, mle_params, names, pi, branch_lengths, h: float = 1e-5):
+    """BEBCalculator.compute_hessian (beb.py:234-296): the whole stencil is one batched evaluation."""
+    x = np.array([mle_params[k] for k in names], dtype=np.float64)
+    pts, single, pair = hessian_points(x, h)
+    f = negative_log_likelihoods(engine, model_class, mle_params, names, pts, pi, branch_lengths)
+    return hessian_from_values(f, single, pair, h)
+
+
+def adaptive_grid(H, names, x, n_grid_points: int = 5):
+    """BEBCalculator.setup_integration_grid (beb.py:298-387): grid along the principal axes of the inverse Hessian,
+    weighted by the normal density there.  The density is evaluated directly: a grid point is x + sum_i o_i s_i v_i with
+    (s_i^2, v_i) the eigenpairs of the covariance, so its Mahalanobis distance is sum_i o_i^2 and the normalising
+    constant drops out of the normalised weights (the reference asks scipy's multivariate_normal for the same number)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    try:
+        cov = np.linalg.inv(H)
+    except np.linalg.LinAlgError:
+        lam, vec = np.linalg.eigh(H)
+        cov = vec @ np.diag(1.0 / np.maximum(lam, 1e-6)) @ vec.T
+    lam, vec = np.linalg.eigh(cov)
+    lam = np.maximum(lam, 1e-10)
+    sd = np.sqrt(lam)
+    offsets = {5: [-2, -1, 0, 1, 2], 3: [-1, 0, 1]}.get(n_grid_points)
+    if offsets is None:
+        offsets = np.linspace(-2, 2, n_grid_points)
+    offsets = np.asarray(offsets, dtype=np.float64)
+    combos = np.stack(np.meshgrid(*([offsets] * n), indexing="ij"), axis=-1).reshape(-1, n)   # itertools.product order
+    points, logw = [], []
+    for o in combos:
+        step = np.zeros(n)
+        for i in range(n):                         # same accumulation order as beb.py:364-366
+            step += o[i] * sd[i] * vec[:, i]
+        pt = x + step
+        if in_bounds(names, pt):
+            points.append(pt)
+            logw.append(-0.5 * float(o @ o))
+    w = np.exp(np.asarray(logw))
+    w = w / w.sum() if w.sum() > 0 else np.full(len(points), 1.0 / len(points))
+    return points, w
+
+
+def adaptive_site_posteriors(engine, model_class, mle_params, names, pi, branch_lengths, n_grid_points: int = 5, h: float = 1e-5,
+                             batch: int = 64):
+    """calculate_beb with grid_type='adaptive' (beb.py:746-796): Hessian, grid, accumulated class posteriors and the
+    posterior mean / SE of omega per site.  Returns (posteriors [S, K], mean omega [S], SE [S], grid points, weights)."""
+    x = np.array([mle_params[k] for k in names], dtype=np.float64)
+    H = hessian(engine, model_class, mle_params, names, pi, branch_lengths, h)
+    points, w = adaptive_grid(H, names, x, n_grid_points)
+    cls = [_class_parameters(model_class, mle_params, names, p, pi) for p in points]
+    post = site_posteriors_over_grid(engine, cls, w, pi, branch_lengths, batch)
+    _, om, _ = _class_parameters(model_class, mle_params, names, x, pi)
+    mean = post @ om
+    se = np.sqrt(np.maximum(post @ om ** 2 - mean ** 2, 0.0))
+    return post, mean, se, points, w

@@ -112,6 +112,32 @@ def main():
                         pi=pi, parent=parent, branch_lengths=bl, sequences=seq, grid_points=np.asarray(pts), weights=wts,
                         grid_kappa=np.asarray([p_[0] for p_ in pts]), grid_omegas=np.asarray([c[1] for c in cls]),
                         grid_proportions=np.asarray([c[0] for c in cls]), tables=np.asarray(tables), posteriors_ref=post8)
+    # ---- the adaptive grid itself: BEBCalculator.compute_hessian and setup_integration_grid (beb.py:234-387) at the
+    #      M2a estimates, three grid points per axis; every likelihood the reference asked for is kept with the
+    #      parameters it was asked at, so that the stencil values, the Hessian and the grid are all pinned ----
+    asked = []
+
+    class CalcH:   # stands in for RustLikelihoodCalculator.compute_log_likelihood_site_classes (likelihood_rust.py:232-298)
+        def compute_log_likelihood_site_classes(self, Q_matrices, pi_, proportions):
+            v = orc.compute_site_class_log_likelihood(list(Q_matrices), proportions, pi_, ts, bl, None, seq, leaf)
+            asked.append((np.stack(Q_matrices), np.asarray(proportions, dtype=np.float64), v))
+            return v
+
+    calc.calc = CalcH()
+    calc.n_grid_points = 3
+    calc.grid_type = "adaptive"
+    with contextlib.redirect_stdout(io.StringIO()):
+        hess = calc.compute_hessian()
+        gpts, gw = calc.setup_integration_grid(hess)
+        calc.calc = Calc()
+        post_ad = calc.compute_site_posteriors(gpts, gw)
+    np.savez_compressed(os.path.join(HERE, "lysozyme_m2a_adaptive_grid.npz"),
+                        pi=pi, parent=parent, branch_lengths=bl, sequences=seq,
+                        param_names=np.array(calc.param_names), mle=calc._params_to_array(mle),
+                        asked_Q0=np.asarray([a[0][0] for a in asked]), asked_proportions=np.asarray([a[1] for a in asked]),
+                        asked_lnl=np.asarray([a[2] for a in asked]), hessian_ref=hess, grid_points_ref=np.asarray(gpts),
+                        weights_ref=np.asarray(gw), posteriors_ref=post_ad)
+    print("adaptive grid fixture:", len(asked), "likelihoods asked,", len(gpts), "grid points; Hessian diagonal", np.round(np.diag(hess), 2))
     print("adaptive-path fixture:", post8.shape, "row sums", post8.sum(axis=1)[:3])
     print("posterior P(omega>1) of the sites PAML lists (15 17 37 41 50 62 114 126):",
           np.round(post[[14, 16, 36, 40, 49, 61, 113, 125], 2], 3))

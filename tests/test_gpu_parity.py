@@ -924,6 +924,39 @@ def test_beb_adaptive_grid_accumulation_against_the_reference(gpu_engine_cls):
     np.testing.assert_allclose(post.sum(axis=1), c["weights"].sum(), atol=1e-12)
 
 
+def test_beb_hessian_stencil_and_adaptive_grid_against_the_reference(gpu_engine_cls):
+    """calculate_beb with grid_type='adaptive' (analysis/beb.py:746-771): the 21 distinct points of the reference's
+    Hessian stencil in one batched call against the 60 likelihoods the reference asked for, the accumulated posteriors
+    over the reference's 30-point grid against the reference's output, and the whole pipeline end to end (Hessian on
+    the device's likelihoods: the stencil's 1/h^2 = 1e10 makes that grid the device's own, see tests/test_beb.py)."""
+    from crabml_amd import beb, models
+    from test_beb import _asked_order
+    c = load_case("lysozyme_m2a_adaptive_grid")
+    names = [str(s) for s in c["param_names"]]
+    mle = dict(zip(names, map(float, c["mle"])))
+    pts, single, pair = beb.hessian_points(c["mle"])
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        f = beb.negative_log_likelihoods(eng, models.M2aCodonModel, mle, names, pts, c["pi"], c["branch_lengths"])
+        outside = np.vstack([pts[:3], [[2.0, 0.3, 2.0, 1.2, 0.1]]])
+        f_out = beb.negative_log_likelihoods(eng, models.M2aCodonModel, mle, names, outside, c["pi"], c["branch_lengths"])
+        H = beb.hessian(eng, models.M2aCodonModel, mle, names, c["pi"], c["branch_lengths"])
+        cls = [beb._class_parameters(models.M2aCodonModel, mle, names, p, c["pi"]) for p in c["grid_points_ref"]]
+        post = beb.site_posteriors_over_grid(eng, cls, c["weights_ref"], c["pi"], c["branch_lengths"])
+        full, mean, se, grid, w = beb.adaptive_site_posteriors(eng, models.M2aCodonModel, mle, names, c["pi"], c["branch_lengths"], 3)
+    for r, lnl in zip(_asked_order(single, pair), c["asked_lnl"]):
+        assert abs(f[r] + lnl) <= SITE_RTOL * abs(lnl), r
+    assert np.isinf(f_out[3]) and np.array_equal(f_out[:3], f[:3])
+    np.testing.assert_array_equal(H, beb.hessian_from_values(f, single, pair))
+    assert np.array_equal(H, H.T)
+    ref = c["posteriors_ref"]
+    big = ref > 1e-8
+    assert np.abs(post - ref).max() <= 1e-11 and np.abs(post[big] / ref[big] - 1.0).max() <= 1e-9
+    assert full.shape == ref.shape and 1 <= len(grid) <= 243 and abs(w.sum() - 1.0) < 1e-12
+    np.testing.assert_allclose(full.sum(axis=1), 1.0, atol=1e-12)
+    om = np.array([min(mle["omega0"], 0.999), 1.0, max(mle["omega2"], 1.001)])
+    assert (mean >= om[0] - 1e-12).all() and (mean <= om[2] + 1e-12).all() and (se >= 0).all()
+
+
 def test_beb_grid_over_pattern_slices_equals_the_whole(gpu_engine_cls):
     """The multi-GPU form of the BEB integration: three pattern slices, their lnfX vectors added, posteriors of each
     slice's own sites from the sum -- together they must tile the whole-alignment result."""
