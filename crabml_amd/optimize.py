@@ -1,0 +1,206 @@
+"""Maximum-likelihood fits with the whole finite-difference gradient in one call.
+
+Mirror of the reference's optimisers for the site-class models (src/crabml/optimize/optimizer.py: M0Optimizer :24-249,
+M1aOptimizer :252-408, M2aOptimizer :411-601): same parameter transforms, bounds, starting values and return values,
+same ``scipy.optimize.minimize(method='L-BFGS-B')`` driver.  The difference is where the gradient comes from.  The
+reference passes no ``jac``, so scipy differentiates numerically: n + 1 sequential calls through the FFI per gradient
+(optimizer.py:225-231).  Here the objective hands scipy ``(f, grad)`` itself: the point and its n forward-difference
+neighbours -- the very points and steps scipy's ``approx_derivative(method='2-point', abs_step=1e-8, bounds=...)``
+would visit, reproduced in :func:`forward_difference_points` and tested bit for bit against scipy -- are one batched
+evaluation through the C ABI (``crab_eval_codon_site_classes`` with B = n + 1; the device builds each distinct
+transition matrix once).  Given equal likelihood values the iterates are therefore the reference's.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import minimize
+
+from . import models
+from .likelihood_rust import RustLikelihoodCalculator
+
+EPS = 1e-8   # scipy's L-BFGS-B default ``eps``, the absolute step of its numerical gradient
+
+
+def forward_difference_points(x, bounds=None, eps: float = EPS):
+    """(points [n, n], dx [n]): row i is x with x_i + h_i, where h follows scipy's rules for an absolute step with
+    bounds -- +eps, flipped to -eps where x_i + eps leaves [lb_i, ub_i] and eps still fits on the other side, else the
+    distance to the farther bound; dx_i = (x_i + h_i) - x_i, the exactly representable step scipy divides by."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    h = np.full(n, float(eps))
+    lost = (x + h) - x == 0                                   # a step lost to rounding falls back to a relative one
+    h[lost] = np.sqrt(np.finfo(np.float64).eps) * np.where(x[lost] >= 0, 1.0, -1.0) * np.maximum(1.0, np.abs(x[lost]))
+    if bounds is not None:
+        lb = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+        ub = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        if not np.all((lb == -np.inf) & (ub == np.inf)):
+            lower, upper = x - lb, ub - x
+            moved = x + h
+            violated = (moved < lb) | (moved > ub)
+            fitting = np.abs(h) <= np.maximum(lower, upper)
+            h[violated & fitting] *= -1
+            fwd = (upper >= lower) & ~fitting
+            h[fwd] = upper[fwd]
+            back = (upper < lower) & ~fitting
+            h[back] = -lower[back]
+    pts = np.tile(x, (n, 1))
+    pts[np.arange(n), np.arange(n)] += h
+    return pts, pts[np.arange(n), np.arange(n)] - x
+
+
+def value_and_gradient(batch_fun, x, bounds=None, eps: float = EPS):
+    """f(x) and its forward-difference gradient from ONE call of ``batch_fun`` on the [n + 1, n] stack of points."""
+    pts, dx = forward_difference_points(x, bounds, eps)
+    f = np.asarray(batch_fun(np.vstack([np.asarray(x, dtype=np.float64)[None, :], pts])), dtype=np.float64)
+    return float(f[0]), (f[1:] - f[0]) / dx
+
+
+def _sigmoid(v):
+    return 1.0 / (1.0 + np.exp(-v))
+
+
+class _SiteClassOptimizer:
+    """What the reference's optimisers share: frequencies, calculator, branch bookkeeping, the scipy driver."""
+
+    n_model = 0                     # leading model parameters before the branch lengths / the branch scale
+    model_bounds: list = []
+
+    def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, init_with_m0: bool = True,
+                 device: int = 0, batched_gradient: bool = True):
+        self.alignment, self.tree = alignment, tree
+        self.init_with_m0, self.device = init_with_m0, device
+        self.use_f3x4, self.optimize_branch_lengths = use_f3x4, optimize_branch_lengths
+        self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device)
+        self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]          # optimizer.py:72
+        self.n_branches = len(self.branch_nodes)
+        self._branch_rows = np.array([self.calc.node_id_map[v] for v in self.branch_nodes])
+        self.batched_gradient = batched_gradient
+        self.history = []
+        self.n_calls = 0            # calls through the C ABI
+        self.n_vectors = 0          # parameter vectors evaluated
+
+    # -- model specifics, per subclass ---------------------------------------------------------
+    def model_at(self, p):          # p: the leading n_model entries of a parameter vector
+        raise NotImplementedError
+
+    def record(self, model, lnl):
+        raise NotImplementedError
+
+    # -- shared ------------------------------------------------------------------------------
+    def _branch_lengths(self, params):
+        """[B, n_nodes] in the boundary's node order (the root's entry stays 0)."""
+        B = params.shape[0]
+        if self.optimize_branch_lengths:
+            bl = np.zeros((B, len(self.calc.tree_structure)))
+            bl[:, self._branch_rows] = np.exp(params[:, self.n_model:self.n_model + self.n_branches])
+            return bl
+        return self.calc._get_current_branch_lengths()[None, :] * np.exp(params[:, self.n_model])[:, None]
+
+    def negative_log_likelihoods(self, params):
+        """The reference's ``compute_log_likelihood`` (e.g. optimizer.py:78-136) for a stack of parameter vectors."""
+        params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        classes = [self.model_at(p[:self.n_model]) for p in params]
+        cls = [m.get_site_classes() for m in classes]
+        lnl = self.calc.engine.codon_site_classes(np.array([m.kappa for m in classes], dtype=np.float64),
+                                                  np.array([c[1] for c in cls], dtype=np.float64),
+                                                  np.array([c[0] for c in cls], dtype=np.float64), self.pi,
+                                                  self._branch_lengths(params))
+        self.n_calls += 1
+        self.n_vectors += len(params)
+        if self.optimize_branch_lengths:                                   # the reference leaves the last values in the tree
+            self.tree.branch_length[np.array(self.branch_nodes)] = np.exp(params[0, self.n_model:self.n_model + self.n_branches])
+        self.history.append(self.record(classes[0], float(lnl[0])))
+        return -lnl
+
+    def compute_log_likelihood(self, params):
+        return float(self.negative_log_likelihoods(np.asarray(params, dtype=np.float64)[None, :])[0])
+
+    def _initial_branch_parameters(self):
+        if not self.optimize_branch_lengths:
+            return [np.log(1.0)], [(np.log(0.01), np.log(100))]
+        init = [float(self.tree.branch_length[v]) for v in self.branch_nodes]
+        if max(init) < 0.001:
+            raise ValueError("the tree has no branch lengths; the reference's least-squares initialisation "
+                             "(optimize/distance_init.py) is outside this path -- give starting lengths")
+        return [np.log(max(b, 0.001)) for b in init], [(np.log(0.0001), np.log(50))] * self.n_branches
+
+    def _minimize(self, init_model, method, maxiter):
+        if self.init_with_m0 and self.optimize_branch_lengths and not isinstance(self, M0Optimizer):   # optimizer.py:346-355
+            m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
+                             batched_gradient=self.batched_gradient)
+            m0.optimize()
+            self.n_calls += m0.n_calls
+            self.n_vectors += m0.n_vectors
+        b0, bb = self._initial_branch_parameters()
+        x0 = np.array(list(init_model) + b0, dtype=np.float64)
+        bounds = list(self.model_bounds) + bb
+        self.history = []
+        if self.batched_gradient and method == "L-BFGS-B":
+            return minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bounds), x0, jac=True,
+                            method=method, bounds=bounds, options={"maxiter": maxiter})
+        return minimize(self.compute_log_likelihood, x0, method=method, bounds=bounds, options={"maxiter": maxiter})
+
+
+class M0Optimizer(_SiteClassOptimizer):
+    """optimizer.py:24-249.  M0 is evaluated as a one-class mixture: same normalisation, same clamp, ln 1 = 0 added."""
+    n_model = 2
+    model_bounds = [(np.log(0.1), np.log(100)), (np.log(0.001), np.log(10))]
+
+    class _OneClass(models._SiteClassModel):
+        def __init__(self, kappa, omega, pi):
+            self.kappa, self.omega, self.pi = kappa, omega, pi
+
+        def get_site_classes(self):
+            return [1.0], [self.omega]
+
+    def model_at(self, p):
+        return self._OneClass(float(np.exp(p[0])), float(np.exp(p[1])), self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "omega": m.omega, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_omega: float = 0.4, method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_omega)], method, maxiter)
+        return float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(-r.fun)
+
+
+class M1aOptimizer(_SiteClassOptimizer):
+    """optimizer.py:252-408."""
+    n_model = 3
+    model_bounds = [(np.log(0.1), np.log(100)), (np.log(0.001), np.log(0.999)), (-10, 10)]
+
+    def model_at(self, p):
+        return models.M1aCodonModel(kappa=float(np.exp(p[0])), omega0=float(np.exp(p[1])), p0=float(_sigmoid(p[2])), pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "omega0": m.omega0, "p0": m.p0, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_omega0: float = 0.5, init_p0: float = 0.7, method: str = "L-BFGS-B",
+                 maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_omega0), np.log(init_p0 / (1 - init_p0))], method, maxiter)
+        return float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(_sigmoid(r.x[2])), float(-r.fun)
+
+
+class M2aOptimizer(_SiteClassOptimizer):
+    """optimizer.py:411-601: p0 and the neutral fraction f of the rest are the free proportions (p1 = (1 - p0) f)."""
+    n_model = 5
+    model_bounds = [(np.log(0.1), np.log(100)), (np.log(0.001), np.log(0.999)), (np.log(1.001), np.log(20)), (-10, 10), (-10, 10)]
+
+    def model_at(self, p):
+        p0 = float(_sigmoid(p[3]))
+        return models.M2aCodonModel(kappa=float(np.exp(p[0])), omega0=float(np.exp(p[1])), omega2=float(np.exp(p[2])),
+                                    p0=p0, p1=(1.0 - p0) * float(_sigmoid(p[4])), pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "omega0": m.omega0, "omega2": m.omega2, "p0": m.p0, "p1": m.p1, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_omega0: float = 0.5, init_omega2: float = 2.0, init_p0: float = 0.5,
+                 init_p1: float = 0.3, method: str = "L-BFGS-B", maxiter: int = 200):
+        f = init_p1 / (1.0 - init_p0) if init_p0 < 1.0 else 0.5
+        f = max(0.01, min(0.99, f))
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_omega0), np.log(init_omega2),
+                                          np.log(init_p0 / (1 - init_p0)), np.log(f / (1 - f))], method, maxiter)
+        p0 = float(_sigmoid(r.x[3]))
+        return (float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(np.exp(r.x[2])), p0, (1.0 - p0) * float(_sigmoid(r.x[4])),
+                float(-r.fun))

@@ -1,0 +1,128 @@
+"""The optimiser mirror (crabml_amd/optimize.py): the gradient stencil against scipy's own, on the CPU; the fits on
+the device (marked gpu) against PAML's optima and against the sequential form the reference uses."""
+import os
+
+import numpy as np
+import pytest
+
+from util import DATA
+
+LYSOZYME_START = ("((Hsa_Human: 0.05, Hla_gibbon: 0.05): 0.05, ((Cgu/Can_colobus: 0.05, Pne_langur: 0.05): 0.05, "
+                  "Mmu_rhesus: 0.05): 0.05, (Ssc_squirrelM: 0.05, Cja_marmoset: 0.05): 0.05);")
+
+
+def _rosen(x):
+    return float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + np.sum(np.cos(3 * x)))
+
+
+def test_forward_difference_stencil_is_scipys_bit_for_bit():
+    """What minimize(method='L-BFGS-B', jac=None) computes (approx_derivative, '2-point', abs_step = eps, bounds) and
+    what value_and_gradient computes from one batched call: same points, same steps, same quotients."""
+    from scipy.optimize._numdiff import approx_derivative
+    from crabml_amd.optimize import forward_difference_points, value_and_gradient
+    rng = np.random.default_rng(0)
+    bounds = [(-2.0, 2.0), (-1.0, 3.0), (None, 1.5), (0.0, None), (-5e-9, 5e-9), (-4.0, 4.0)]
+    lb = np.array([-np.inf if b[0] is None else b[0] for b in bounds])
+    ub = np.array([np.inf if b[1] is None else b[1] for b in bounds])
+    cases = [rng.uniform(-0.5, 0.5, 6) for _ in range(20)]
+    cases += [np.array([2.0, 3.0, 1.5, 0.0, 5e-9, -4.0]),            # on the bounds: steps flip
+              np.array([2.0 - 5e-9, -1.0, 1.5 - 1e-9, 1e3, 0.0, 4.0 - 1e-8]),
+              np.array([1.0, 1e9, -1e12, 1e17, 0.0, 0.0])]          # steps lost to rounding fall back to relative ones
+    cases[-1][3] = 1e17
+    for x in cases:
+        x = np.clip(x, lb, ub) if not np.any(np.abs(x) > 1e6) else x
+        use_bounds = not np.any(np.abs(x) > 1e6)
+        seen = []
+
+        def fun(v):
+            seen.append(v.copy())
+            return _rosen(v)
+
+        ref = approx_derivative(fun, x, method="2-point", abs_step=1e-8, f0=_rosen(x), bounds=(lb, ub) if use_bounds else (-np.inf, np.inf))
+        pts, dx = forward_difference_points(x, bounds if use_bounds else None)
+        np.testing.assert_array_equal(pts, np.array(seen))
+        f, g = value_and_gradient(lambda P: np.array([_rosen(p) for p in P]), x, bounds if use_bounds else None)
+        assert f == _rosen(x)
+        np.testing.assert_array_equal(g, ref)
+
+
+def test_batched_gradient_gives_scipys_own_trajectory():
+    from scipy.optimize import minimize
+    from crabml_amd.optimize import value_and_gradient
+    bounds = [(-1.5, 1.5)] * 5 + [(0.2, 0.9)]
+    x0 = np.array([-1.0, 1.2, 0.3, -0.2, 1.5, 0.9])
+    calls = []
+
+    def batch(P):
+        calls.append(len(P))
+        return np.array([_rosen(p) for p in P])
+
+    a = minimize(_rosen, x0, method="L-BFGS-B", bounds=bounds, options={"maxiter": 200})
+    b = minimize(lambda x: value_and_gradient(batch, x, bounds), x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": 200})
+    np.testing.assert_array_equal(a.x, b.x)
+    assert a.fun == b.fun and a.nit == b.nit
+    assert set(calls) == {7} and a.nfev == 7 * len(calls)          # n + 1 sequential evaluations became one call each
+
+
+def _lysozyme():
+    from crabml_amd.io import Alignment, Tree
+    return Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"), seqtype="codon"), Tree.from_newick(LYSOZYME_START)
+
+
+@pytest.mark.gpu
+def test_m0_fit_reaches_pamls_optimum_and_equals_the_sequential_fit():
+    """tests/test_reference/test_paml_m0.py:30-72 (the reference accepts |lnL - PAML| < 10; a converged fit is within
+    1e-3).  The batched-gradient fit and the reference's form of it (scipy differentiating through n + 1 single calls)
+    see bit-identical likelihoods, so they take the same path to the same point."""
+    from crabml_amd.optimize import M0Optimizer
+    aln, tree = _lysozyme()
+    opt = M0Optimizer(aln, tree, use_f3x4=True, optimize_branch_lengths=True)
+    kappa, omega, lnl = opt.optimize(init_kappa=2.0, init_omega=0.4)
+    assert abs(lnl - (-906.017440)) < 1e-3
+    assert abs(kappa - 4.54008) < 5e-2 and abs(omega - 0.80663) < 5e-3          # lysozyme M0 estimates, PAML's mlc
+    assert opt.n_vectors == opt.n_calls * (2 + opt.n_branches + 1) and opt.n_branches == 11
+    assert opt.history[-1]["log_likelihood"] >= opt.history[0]["log_likelihood"]
+    aln2, tree2 = _lysozyme()
+    seq = M0Optimizer(aln2, tree2, batched_gradient=False)
+    k2, w2, l2 = seq.optimize(init_kappa=2.0, init_omega=0.4)
+    assert (k2, w2, l2) == (kappa, omega, lnl)
+    np.testing.assert_array_equal(seq.result.x, opt.result.x)
+    assert seq.n_calls == opt.n_vectors and seq.result.nit == opt.result.nit
+    # the tree keeps the lengths of the last point evaluated: the optimum's neighbourhood for both, but the sequential
+    # form (like the reference) ends on a finite-difference neighbour, one length off by its 1e-8 step
+    np.testing.assert_allclose(tree.branch_length, tree2.branch_length, rtol=2e-8)
+    assert np.abs(np.log(tree.branch_length[np.array(opt.branch_nodes)]) - opt.result.x[2:]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_m1a_and_m2a_fits_reach_pamls_optima():
+    """tests/test_reference/test_site_class_optimizers.py, with branch lengths free and the M0 start the reference
+    defaults to; PAML: M1a -902.503872, M2a -899.998568 (tests/test_rust/test_paml_rust_validation.py:104,164).  L-BFGS-B with scipy's
+    default stopping rule and a forward-difference gradient stops a few 1e-3 short of PAML's optimum on the mixtures
+    (the reference's driver, unchanged); the reference's own tests only ask for a finite, improved likelihood."""
+    from crabml_amd.optimize import M1aOptimizer, M2aOptimizer
+    aln, tree = _lysozyme()
+    m1 = M1aOptimizer(aln, tree)
+    kappa, omega0, p0, l1 = m1.optimize()
+    assert abs(l1 - (-902.503872)) < 2e-2 and 0 < omega0 < 1 and 0 < p0 < 1 and kappa > 0
+    aln, tree = _lysozyme()
+    m2 = M2aOptimizer(aln, tree)
+    kappa, omega0, omega2, p0, p1, l2 = m2.optimize()
+    assert abs(l2 - (-899.998568)) < 2e-2
+    assert 0 < omega0 < 1 < omega2 and 0 < p0 < 1 and 0 < p1 < 1 and 0 < 1 - p0 - p1 < 1
+    assert l2 >= l1 - 1e-6
+    # mixtures too: batched and sequential gradients walk the same path from the same start (with the M0 start they need
+    # not: the sequential M0 fit, like the reference's, leaves the tree on a finite-difference neighbour of its optimum)
+    runs = []
+    for batched in (True, False):
+        aln, tree = _lysozyme()
+        o = M2aOptimizer(aln, tree, init_with_m0=False, batched_gradient=batched)
+        runs.append((o.optimize(), o.result.x, o.result.nit))
+    assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    # global branch scale instead of free branch lengths (test_site_class_optimizers.py:74-99)
+    aln, tree = _lysozyme()
+    m2s = M2aOptimizer(aln, tree, optimize_branch_lengths=False)
+    out = m2s.optimize(maxiter=50)
+    assert np.isfinite(out[-1]) and out[-1] <= l2 + 1e-6 and out[-1] >= m2s.history[0]["log_likelihood"]
+    assert m2s.n_vectors == m2s.n_calls * 7
