@@ -11,6 +11,8 @@ vectorised restatement around a precomputed 61x61 neighbour mask.
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from .io import CODONS, GENETIC_CODE, N_CODONS
@@ -175,14 +177,20 @@ class M5CodonModel(_SiteClassModel):
         return [1.0 / K] * K, _median_quantiles(lambda p: gamma.ppf(p, self.alpha, scale=1.0 / self.beta), K)
 
 
+@functools.lru_cache(maxsize=256)
+def _beta_quantiles(p_beta, q_beta, K):
+    """Median quantiles of Beta(p, q); remembered, because the rows of a finite-difference stencil mostly share them."""
+    from scipy.stats import beta
+    return tuple(_median_quantiles(lambda p: beta.ppf(p, p_beta, q_beta), K))
+
+
 class M7CodonModel(_SiteClassModel):
     def __init__(self, kappa=2.0, p_beta=0.5, q_beta=0.5, ncatG=10, pi=None):
         self.kappa, self.p_beta, self.q_beta, self.ncatG = kappa, max(p_beta, 0.005), max(q_beta, 0.005), ncatG
         self.pi = _normalise_pi(pi)
 
     def _beta_omegas(self):
-        from scipy.stats import beta
-        return _median_quantiles(lambda p: beta.ppf(p, self.p_beta, self.q_beta), self.ncatG)
+        return list(_beta_quantiles(self.p_beta, self.q_beta, self.ncatG))
 
     def get_site_classes(self):
         K = self.ncatG

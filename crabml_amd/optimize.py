@@ -1,7 +1,7 @@
 """Maximum-likelihood fits with the whole finite-difference gradient in one call.
 
 Mirror of the reference's optimisers for the site-class models (src/crabml/optimize/optimizer.py: M0Optimizer :24-249,
-M1aOptimizer :252-408, M2aOptimizer :411-601): same parameter transforms, bounds, starting values and return values,
+M1aOptimizer :252-408, M2aOptimizer :411-601, M7Optimizer :867-1029, M8Optimizer :1032-1218, M8aOptimizer :1221-1412): same parameter transforms, bounds, starting values and return values,
 same ``scipy.optimize.minimize(method='L-BFGS-B')`` driver.  The difference is where the gradient comes from.  The
 reference passes no ``jac``, so scipy differentiates numerically: n + 1 sequential calls through the FFI per gradient
 (optimizer.py:225-231).  Here the objective hands scipy ``(f, grad)`` itself: the point and its n forward-difference
@@ -204,3 +204,67 @@ class M2aOptimizer(_SiteClassOptimizer):
         p0 = float(_sigmoid(r.x[3]))
         return (float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(np.exp(r.x[2])), p0, (1.0 - p0) * float(_sigmoid(r.x[4])),
                 float(-r.fun))
+
+
+_BETA_BOUND = (np.log(0.005), np.log(99))
+
+
+class M7Optimizer(_SiteClassOptimizer):
+    """optimizer.py:867-1029: kappa and the two beta shape parameters; ``ncatG`` equal-weight median quantiles."""
+    n_model = 3
+    model_bounds = [(np.log(0.1), np.log(100)), _BETA_BOUND, _BETA_BOUND]
+
+    def __init__(self, alignment, tree, ncatG: int = 10, **kw):
+        super().__init__(alignment, tree, **kw)
+        self.ncatG = ncatG
+
+    def model_at(self, p):
+        return models.M7CodonModel(kappa=float(np.exp(p[0])), p_beta=float(np.exp(p[1])), q_beta=float(np.exp(p[2])),
+                                   ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "p_beta": m.p_beta, "q_beta": m.q_beta, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_p_beta: float = 0.5, init_q_beta: float = 0.5, method: str = "L-BFGS-B",
+                 maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_p_beta), np.log(init_q_beta)], method, maxiter)
+        return float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(np.exp(r.x[2])), float(-r.fun)
+
+
+class M8Optimizer(M7Optimizer):
+    """optimizer.py:1032-1218: M7's beta classes with weight p0 plus one class omega_s > 1."""
+    n_model = 5
+    model_bounds = [(np.log(0.1), np.log(100)), (-10, 10), _BETA_BOUND, _BETA_BOUND, (np.log(1.001), np.log(20))]
+
+    def model_at(self, p):
+        return models.M8CodonModel(kappa=float(np.exp(p[0])), p0=float(_sigmoid(p[1])), p_beta=float(np.exp(p[2])),
+                                   q_beta=float(np.exp(p[3])), omega_s=float(np.exp(p[4])), ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "p0": m.p0, "p_beta": m.p_beta, "q_beta": m.q_beta, "omega_s": m.omega_s, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_p0: float = 0.9, init_p_beta: float = 0.7, init_q_beta: float = 1.5,
+                 init_omega_s: float = 2.5, method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_p0 / (1 - init_p0)), np.log(init_p_beta),
+                                          np.log(init_q_beta), np.log(init_omega_s)], method, maxiter)
+        return (float(np.exp(r.x[0])), float(_sigmoid(r.x[1])), float(np.exp(r.x[2])), float(np.exp(r.x[3])), float(np.exp(r.x[4])),
+                float(-r.fun))
+
+
+class M8aOptimizer(M7Optimizer):
+    """optimizer.py:1221-1412: M8 with omega_s fixed at 1, the null of the M8a-M8 test."""
+    n_model = 4
+    model_bounds = [(np.log(0.1), np.log(100)), (-10, 10), _BETA_BOUND, _BETA_BOUND]
+
+    def model_at(self, p):
+        return models.M8aCodonModel(kappa=float(np.exp(p[0])), p0=float(_sigmoid(p[1])), p_beta=float(np.exp(p[2])),
+                                    q_beta=float(np.exp(p[3])), ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "p0": m.p0, "p_beta": m.p_beta, "q_beta": m.q_beta, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_p0: float = 0.9, init_p_beta: float = 0.7, init_q_beta: float = 1.5,
+                 method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_p0 / (1 - init_p0)), np.log(init_p_beta),
+                                          np.log(init_q_beta)], method, maxiter)
+        return float(np.exp(r.x[0])), float(_sigmoid(r.x[1])), float(np.exp(r.x[2])), float(np.exp(r.x[3])), float(-r.fun)

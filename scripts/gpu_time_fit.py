@@ -10,9 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_optimize import _lysozyme   # noqa: E402
 
-from crabml_amd.optimize import M0Optimizer, M1aOptimizer, M2aOptimizer   # noqa: E402
+from crabml_amd.optimize import M0Optimizer, M1aOptimizer, M2aOptimizer, M7Optimizer, M8aOptimizer, M8Optimizer   # noqa: E402
 
-for cls in (M0Optimizer, M1aOptimizer, M2aOptimizer):
+for cls in (M0Optimizer, M1aOptimizer, M2aOptimizer, M7Optimizer, M8Optimizer, M8aOptimizer):
     for batched in (True, False, True, False):
         aln, tree = _lysozyme()
         opt = cls(aln, tree, batched_gradient=batched)

@@ -126,3 +126,23 @@ def test_m1a_and_m2a_fits_reach_pamls_optima():
     out = m2s.optimize(maxiter=50)
     assert np.isfinite(out[-1]) and out[-1] <= l2 + 1e-6 and out[-1] >= m2s.history[0]["log_likelihood"]
     assert m2s.n_vectors == m2s.n_calls * 7
+
+
+@pytest.mark.gpu
+def test_m7_m8_m8a_fits_and_their_likelihood_ratio_tests():
+    """The M7-M8 and M8a-M8 comparisons on lysozyme (BASELINE config 5 runs the first per gene).  PAML's optima:
+    M7 -902.510018, M8 -899.999237, M8a -902.503869 (tests/test_rust/test_paml_rust_validation.py:387,445,509)."""
+    from crabml_amd.optimize import M7Optimizer, M8aOptimizer, M8Optimizer
+    fits = {}
+    for cls in (M7Optimizer, M8Optimizer, M8aOptimizer):
+        aln, tree = _lysozyme()
+        opt = cls(aln, tree)
+        fits[cls.__name__] = (opt.optimize(), opt)
+    l7, l8, l8a = (fits[k][0][-1] for k in ("M7Optimizer", "M8Optimizer", "M8aOptimizer"))
+    assert abs(l7 - (-902.510018)) < 5e-2 and abs(l8 - (-899.999237)) < 5e-2 and abs(l8a - (-902.503869)) < 5e-2
+    assert l8 >= l7 - 1e-6 and l8 >= l8a - 1e-6                       # nested models
+    assert abs(2 * (l8 - l7) - 2 * (-899.999237 + 902.510018)) < 0.1   # the test statistic PAML's numbers give
+    kappa, p0, p_beta, q_beta, omega_s, _ = fits["M8Optimizer"][0]
+    assert omega_s > 1 and 0 < p0 < 1 and p_beta > 0 and q_beta > 0 and kappa > 0
+    o8 = fits["M8Optimizer"][1]
+    assert o8.history and all(np.isfinite(h["log_likelihood"]) for h in o8.history)
