@@ -66,12 +66,12 @@ class _SiteClassOptimizer:
     model_bounds: list = []
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, init_with_m0: bool = True,
-                 device: int = 0, batched_gradient: bool = True):
+                 device: int = 0, batched_gradient: bool = True, engine=None):
         self.alignment, self.tree = alignment, tree
-        self.init_with_m0, self.device = init_with_m0, device
+        self.init_with_m0, self.device, self.engine = init_with_m0, device, engine
         self.use_f3x4, self.optimize_branch_lengths = use_f3x4, optimize_branch_lengths
         self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
-        self.calc = RustLikelihoodCalculator(alignment, tree, device=device)
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)   # engine: one to re-target, e.g. a scan worker's
         self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]          # optimizer.py:72
         self.n_branches = len(self.branch_nodes)
         self._branch_rows = np.array([self.calc.node_id_map[v] for v in self.branch_nodes])
@@ -100,12 +100,16 @@ class _SiteClassOptimizer:
     def negative_log_likelihoods(self, params):
         """The reference's ``compute_log_likelihood`` (e.g. optimizer.py:78-136) for a stack of parameter vectors."""
         params = np.atleast_2d(np.asarray(params, dtype=np.float64))
-        classes = [self.model_at(p[:self.n_model]) for p in params]
-        cls = [m.get_site_classes() for m in classes]
-        lnl = self.calc.engine.codon_site_classes(np.array([m.kappa for m in classes], dtype=np.float64),
-                                                  np.array([c[1] for c in cls], dtype=np.float64),
-                                                  np.array([c[0] for c in cls], dtype=np.float64), self.pi,
+        # the rows of a stencil mostly share their model parameters (all the branch-length rows do): one model each
+        lead, row_model = np.unique(params[:, :self.n_model], axis=0, return_inverse=True)
+        row_model = row_model.reshape(-1)
+        distinct = [self.model_at(p) for p in lead]
+        cls = [m.get_site_classes() for m in distinct]
+        lnl = self.calc.engine.codon_site_classes(np.array([m.kappa for m in distinct], dtype=np.float64)[row_model],
+                                                  np.array([c[1] for c in cls], dtype=np.float64)[row_model],
+                                                  np.array([c[0] for c in cls], dtype=np.float64)[row_model], self.pi,
                                                   self._branch_lengths(params))
+        classes = [distinct[row_model[0]]]
         self.n_calls += 1
         self.n_vectors += len(params)
         if self.optimize_branch_lengths:                                   # the reference leaves the last values in the tree
@@ -128,7 +132,7 @@ class _SiteClassOptimizer:
     def _minimize(self, init_model, method, maxiter):
         if self.init_with_m0 and self.optimize_branch_lengths and not isinstance(self, M0Optimizer):   # optimizer.py:346-355
             m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
-                             batched_gradient=self.batched_gradient)
+                             batched_gradient=self.batched_gradient, engine=self.engine)
             m0.optimize()
             self.n_calls += m0.n_calls
             self.n_vectors += m0.n_vectors

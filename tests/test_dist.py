@@ -9,7 +9,7 @@ import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from util import leaf_ids, load_case, tree_structure
+from util import DATA, leaf_ids, load_case, tree_structure
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -180,3 +180,85 @@ def test_two_rank_gloo_beb_grid_over_pattern_slices():
         res = [out[r] for r in range(world)]
     assert all(r[0] and r[1] and r[2] for r in res)
     assert res[0][3] == res[1][3]          # rank-ordered sum: the same ln f(X) bits on every rank
+
+
+class _OracleEngine:
+    """The calls the optimiser mirror makes on an Engine, answered by the CPU oracle (CPU tests only)."""
+
+    def __init__(self, *_):
+        self.closed = False
+
+    def set_tree_structure(self, tree_structure, leaf_node_ids):
+        self.ts, self.leaf = list(tree_structure), list(leaf_node_ids)
+
+    def set_alignment(self, codes, **_):
+        self.codes = np.asarray(codes)
+
+    def codon_site_classes(self, kappa, omegas, proportions, pi, branch_lengths, no_clamp=False):
+        from crabml_amd import models
+        from oracle import oracle as orc
+        out = []
+        for k, om, pr, bl in zip(kappa, omegas, proportions, branch_lengths):
+            raw = [models.build_codon_Q_matrix(float(k), float(w), pi, 1.0) for w in om]
+            scale = sum(p * models.mean_rate(Q, pi) for p, Q in zip(pr, raw))
+            out.append(orc.compute_site_class_log_likelihood([Q / scale for Q in raw], pr, pi, self.ts, bl, None, self.codes, self.leaf,
+                                                             threads=1))
+        return np.array(out)
+
+    def close(self):
+        self.closed = True
+
+
+def _scan_genes():
+    from crabml_amd.io import Alignment, Tree
+    from test_optimize import LYSOZYME_START
+    aln = Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"), seqtype="codon")
+    codes = np.asarray(aln.sequences)
+    return [(Alignment.from_codes(aln.names, codes[:, lo:lo + 30]), Tree.from_newick(LYSOZYME_START)) for lo in (0, 30, 60, 90)]
+
+
+def _scan_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crabml_amd import scan
+        rows = scan.scan(_scan_genes(), null="M7", rank=rank, world_size=world, workers=2, make_engine=_OracleEngine, ncatG=2, maxiter=2, init_with_m0=False)
+        out[rank] = [(r["lnL_null"], r["lnL_M8"], r["LRT"], r["pvalue"]) for r in rows]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gene_scan_equals_the_single_rank_scan():
+    """BASELINE config 5's shape in small: genes dealt round-robin to ranks, M7 and M8 fitted per gene through the optimiser
+    mirror (two iterations, two beta classes: the fit itself is tested on the device), rows gathered on every rank."""
+    from crabml_amd import scan
+    import warnings
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_scan_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        alone = [(r["lnL_null"], r["lnL_M8"], r["LRT"], r["pvalue"])
+                 for r in scan.scan(_scan_genes(), null="M7", workers=1, make_engine=_OracleEngine, ncatG=2, maxiter=2, init_with_m0=False)]
+    assert res[0] == res[1] == alone and len(alone) == 4
+    for l7, l8, stat, p in alone:
+        assert np.isfinite(l7) and np.isfinite(l8) and stat >= 0 and 0 <= p <= 1
+        assert stat == max(0.0, 2 * (l8 - l7))
+
+
+def test_lrt_statistics_follow_the_reference():
+    """analysis/lrt.py:8-138: chi-square tail, the boundary mixture's halved tail, and the negative-statistic guard."""
+    from scipy.stats import chi2
+    from crabml_amd.scan import calculate_lrt, calculate_lrt_mixture
+    assert calculate_lrt(-902.510018, -899.999237, 2) == (2 * (-899.999237 + 902.510018), chi2.sf(2 * (-899.999237 + 902.510018), 2))
+    stat, p = calculate_lrt_mixture(-902.503869, -899.999237, 1)
+    assert p == 0.5 * chi2.sf(stat, 1) and abs(stat - 5.009264) < 1e-6
+    assert calculate_lrt(-10.0, -10.0, 2) == (0.0, 1.0) and calculate_lrt_mixture(-10.0, -10.0, 1) == (0.0, 1.0)
+    with pytest.warns(UserWarning, match="Negative LRT"):
+        assert calculate_lrt(-10.0, -10.5, 2) == (0.0, 1.0)
+    with pytest.warns(UserWarning, match="Negative LRT"):
+        assert calculate_lrt_mixture(-10.0, -10.5, 1) == (0.0, 1.0)
