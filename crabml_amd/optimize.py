@@ -1,7 +1,8 @@
 """Maximum-likelihood fits with the whole finite-difference gradient in one call.
 
 Mirror of the reference's optimisers for the site-class models (src/crabml/optimize/optimizer.py: M0Optimizer :24-249,
-M1aOptimizer :252-408, M2aOptimizer :411-601, M7Optimizer :867-1029, M8Optimizer :1032-1218, M8aOptimizer :1221-1412): same parameter transforms, bounds, starting values and return values,
+M1aOptimizer :252-408, M2aOptimizer :411-601, M7Optimizer :867-1029, M8Optimizer :1032-1218, M8aOptimizer :1221-1412;
+src/crabml/optimize/branch_site.py: BranchSiteModelAOptimizer): same parameter transforms, bounds, starting values and return values,
 same ``scipy.optimize.minimize(method='L-BFGS-B')`` driver.  The difference is where the gradient comes from.  The
 reference passes no ``jac``, so scipy differentiates numerically: n + 1 sequential calls through the FFI per gradient
 (optimizer.py:225-231).  Here the objective hands scipy ``(f, grad)`` itself: the point and its n forward-difference
@@ -272,3 +273,100 @@ class M8aOptimizer(M7Optimizer):
         self.result = r = self._minimize([np.log(init_kappa), np.log(init_p0 / (1 - init_p0)), np.log(init_p_beta),
                                           np.log(init_q_beta)], method, maxiter)
         return float(np.exp(r.x[0])), float(_sigmoid(r.x[1])), float(np.exp(r.x[2])), float(np.exp(r.x[3])), float(-r.fun)
+
+
+class BranchSiteModelAOptimizer:
+    """optimize/branch_site.py:17-398 -- Model A (``fix_omega=False``) and its null (omega2 = 1).
+
+    One behaviour of the reference is kept on purpose, because results depend on it: its objective hands the FFI
+    ``calc.branch_lengths_template``, the lengths the tree had when the calculator was built (branch_site.py:180,
+    likelihood_rust.py:124-132), not the lengths it has just written into the tree from the parameter vector (:143-150).
+    The branch-length parameters therefore never reach the likelihood: their gradient components are zero, L-BFGS-B
+    leaves them where they started, and the fit is over (kappa, omega0[, omega2], p0, p1) on the input tree's lengths --
+    yet every numerical gradient still pays one evaluation per branch.  Here the rows of a stencil that evaluate to the
+    same thing are evaluated once (rows are compared on what reaches the likelihood), so a gradient is 5 or 6 distinct
+    vectors in one call whatever the size of the tree.  ``live_branch_lengths=True`` instead lets the branch-length
+    parameters through (what the docstring of the reference promises); every row is then distinct."""
+
+    def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, fix_omega: bool = False,
+                 device: int = 0, batched_gradient: bool = True, engine=None, live_branch_lengths: bool = False):
+        self.alignment, self.tree = alignment, tree
+        self.use_f3x4, self.optimize_branch_lengths, self.fix_omega = use_f3x4, optimize_branch_lengths, fix_omega
+        self.batched_gradient, self.live_branch_lengths = batched_gradient, live_branch_lengths
+        self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)
+        self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]
+        self.n_branches = len(self.branch_nodes)
+        self._branch_rows = np.array([self.calc.node_id_map[v] for v in self.branch_nodes])
+        self.branch_labels = tree.branch_labels()
+        self.branch_labels_u8 = self.calc.renumber_branch_labels()                       # branch_site.py:79-90
+        self.model = models.BranchSiteModelA(self.pi, self.branch_labels, fix_omega=fix_omega)   # validates the labels
+        self.n_model = 4 if fix_omega else 5
+        self._template = np.asarray(self.calc.branch_lengths_template, dtype=np.float64)
+        self.history = []
+        self.n_calls = self.n_vectors = self.n_rows = 0
+
+    def _unpack(self, p):
+        """(kappa, omega0, omega2, p0, p1) of one parameter vector, branch_site.py:116-139."""
+        kappa, omega0 = float(np.exp(p[0])), float(np.exp(p[1]))
+        omega2, at = (1.0, 2) if self.fix_omega else (float(np.exp(p[2])), 3)
+        p0, p1 = float(_sigmoid(p[at])), float(_sigmoid(p[at + 1]))
+        total = p0 + p1
+        if total >= 0.999:
+            p0, p1 = p0 / total * 0.999, p1 / total * 0.999
+        return kappa, omega0, omega2, p0, p1
+
+    def _branch_lengths(self, params):
+        B = params.shape[0]
+        if not self.live_branch_lengths:
+            return np.broadcast_to(self._template, (B, len(self._template)))
+        if self.optimize_branch_lengths:
+            bl = np.zeros((B, len(self._template)))
+            bl[:, self._branch_rows] = np.exp(params[:, self.n_model:self.n_model + self.n_branches])
+            return bl
+        return self._template[None, :] * np.exp(params[:, self.n_model])[:, None]
+
+    def negative_log_likelihoods(self, params):
+        params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        reaching = params if self.live_branch_lengths else params[:, :self.n_model]
+        distinct, first, row_of = np.unique(reaching, axis=0, return_index=True, return_inverse=True)
+        row_of = row_of.reshape(-1)
+        rows = params[first]
+        q = np.array([self._unpack(p) for p in rows])
+        lnl = self.calc.engine.codon_branch_site(q[:, 0], q[:, 1], q[:, 2], q[:, 3], q[:, 4], self.pi,
+                                                 np.ascontiguousarray(self._branch_lengths(rows)), self.branch_labels_u8)
+        self.n_calls += 1
+        self.n_vectors += len(rows)
+        self.n_rows += len(params)
+        if self.optimize_branch_lengths:                                   # branch_site.py:143-145: written, not read back
+            self.tree.branch_length[np.array(self.branch_nodes)] = np.exp(params[0, self.n_model:self.n_model + self.n_branches])
+        lnl = np.asarray(lnl, dtype=np.float64)[row_of]
+        k, w0, w2, p0, p1 = self._unpack(params[0])
+        self.history.append({"kappa": k, "omega0": w0, "omega2": w2, "p0": p0, "p1": p1, "log_likelihood": float(lnl[0])})
+        return -lnl
+
+    def compute_log_likelihood(self, params):
+        return float(self.negative_log_likelihoods(np.asarray(params, dtype=np.float64)[None, :])[0])
+
+    def optimize(self, init_kappa: float = 2.0, init_omega0: float = 0.1, init_omega2: float = 2.0, init_p0: float = 0.3,
+                 init_p1: float = 0.3, method: str = "L-BFGS-B", maxiter: int = 300):
+        lead = [np.log(init_kappa), np.log(init_omega0)] + ([] if self.fix_omega else [np.log(init_omega2)]) + \
+               [np.log(init_p0 / (1 - init_p0)), np.log(init_p1 / (1 - init_p1))]
+        bounds = [(np.log(0.1), np.log(100)), (np.log(0.001), np.log(0.999))] + \
+                 ([] if self.fix_omega else [(np.log(1.001), np.log(20))]) + [(-10, 10), (-10, 10)]
+        if self.optimize_branch_lengths:
+            lead += [np.log(max(float(self.tree.branch_length[v]), 0.001)) for v in self.branch_nodes]
+            bounds += [(np.log(0.0001), np.log(50))] * self.n_branches
+        else:
+            lead += [np.log(1.0)]
+            bounds += [(np.log(0.01), np.log(100))]
+        x0 = np.array(lead, dtype=np.float64)
+        self.history = []
+        if self.batched_gradient and method == "L-BFGS-B":
+            r = minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bounds), x0, jac=True, method=method,
+                         bounds=bounds, options={"maxiter": maxiter, "disp": False})
+        else:
+            r = minimize(self.compute_log_likelihood, x0, method=method, bounds=bounds, options={"maxiter": maxiter, "disp": False})
+        self.result = r
+        kappa, omega0, omega2, p0, p1 = self._unpack(r.x)
+        return kappa, omega0, omega2, p0, p1, float(-r.fun)

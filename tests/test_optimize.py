@@ -146,3 +146,45 @@ def test_m7_m8_m8a_fits_and_their_likelihood_ratio_tests():
     assert omega_s > 1 and 0 < p0 < 1 and p_beta > 0 and q_beta > 0 and kappa > 0
     o8 = fits["M8Optimizer"][1]
     assert o8.history and all(np.isfinite(h["log_likelihood"]) for h in o8.history)
+
+
+def _lysozyme_large():
+    from crabml_amd.io import Alignment, Tree
+    return (Alignment.from_phylip(os.path.join(DATA, "lysozymeLarge_clean.nuc"), seqtype="codon"),
+            Tree.from_newick(open(os.path.join(DATA, "lysozymeLarge.trees")).read()))
+
+
+@pytest.mark.gpu
+def test_branch_site_model_a_fit_against_paml():
+    """tests/test_branch_site_optimization.py:23-86 (same start, same tolerances) and the null of
+    tests/test_branch_site_null.py.  The reference's objective never reads the branch-length parameters (see the class
+    docstring), so the 33 branch rows of each stencil collapse onto the centre row: 6 distinct vectors per gradient."""
+    from crabml_amd.optimize import BranchSiteModelAOptimizer
+    aln, tree = _lysozyme_large()
+    start = tree.branch_length.copy()
+    opt = BranchSiteModelAOptimizer(aln, tree, use_f3x4=True, optimize_branch_lengths=True)
+    kappa, omega0, omega2, p0, p1, lnl = opt.optimize(init_kappa=3.0, init_omega0=0.05, init_omega2=3.0, init_p0=0.35, init_p1=0.30,
+                                                      method="L-BFGS-B", maxiter=500)
+    assert abs(lnl - (-1035.533916)) < 0.1
+    assert abs(kappa - 4.154927) < 0.1 and abs(p0 - 0.326513) < 0.05 and abs(p1 - 0.269308) < 0.05
+    assert 0 < omega0 < 0.01 and omega2 > 1.0 and abs(omega2 - 4.809765) < 0.5
+    assert opt.n_branches == 33 and opt.n_rows == opt.n_calls * (5 + 33 + 1) and opt.n_vectors == opt.n_calls * 6
+    # the lengths never moved; what the tree holds afterwards is the parameter vector's max(length, 0.001), written but not read
+    moved = np.where(np.asarray(tree.parent) >= 0, np.maximum(start, 0.001), start)
+    np.testing.assert_allclose(tree.branch_length, moved, rtol=0, atol=2e-8)
+    assert np.all(opt.result.x[5:] == np.log(np.maximum(start[np.array(opt.branch_nodes)], 0.001)))
+    # the sequential form, as the reference runs it: the same iterates, 39 calls per gradient instead of one
+    aln2, tree2 = _lysozyme_large()
+    seq = BranchSiteModelAOptimizer(aln2, tree2, batched_gradient=False)
+    out2 = seq.optimize(init_kappa=3.0, init_omega0=0.05, init_omega2=3.0, init_p0=0.35, init_p1=0.30, maxiter=500)
+    assert out2 == (kappa, omega0, omega2, p0, p1, lnl) and seq.n_calls == opt.n_rows
+    # null model and the test between them
+    aln3, tree3 = _lysozyme_large()
+    null = BranchSiteModelAOptimizer(aln3, tree3, fix_omega=True)
+    *_, w2_null, _, _, l0 = null.optimize(init_kappa=3.0, init_omega0=0.05, init_p0=0.35, init_p1=0.30, maxiter=500)
+    assert w2_null == 1.0 and l0 <= lnl + 1e-6 and null.n_vectors == null.n_calls * 5
+    # branch lengths let through: starts from max(length, 0.001) on the seven zero-length branches, ends near PAML's optimum too
+    aln4, tree4 = _lysozyme_large()
+    live = BranchSiteModelAOptimizer(aln4, tree4, live_branch_lengths=True)
+    l_live = live.optimize(init_kappa=3.0, init_omega0=0.05, init_omega2=3.0, init_p0=0.35, init_p1=0.30, maxiter=500)[-1]
+    assert abs(l_live - (-1035.533916)) < 0.2 and live.n_vectors == live.n_rows
