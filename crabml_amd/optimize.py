@@ -2,7 +2,7 @@
 
 Mirror of the reference's optimisers for the site-class models (src/crabml/optimize/optimizer.py: M0Optimizer :24-249,
 M1aOptimizer :252-408, M2aOptimizer :411-601, M7Optimizer :867-1029, M8Optimizer :1032-1218, M8aOptimizer :1221-1412;
-src/crabml/optimize/branch_site.py: BranchSiteModelAOptimizer): same parameter transforms, bounds, starting values and return values,
+src/crabml/optimize/branch_site.py: BranchSiteModelAOptimizer; src/crabml/optimize/branch.py: BranchModelOptimizer): same parameter transforms, bounds, starting values and return values,
 same ``scipy.optimize.minimize(method='L-BFGS-B')`` driver.  The difference is where the gradient comes from.  The
 reference passes no ``jac``, so scipy differentiates numerically: n + 1 sequential calls through the FFI per gradient
 (optimizer.py:225-231).  Here the objective hands scipy ``(f, grad)`` itself: the point and its n forward-difference
@@ -370,3 +370,65 @@ class BranchSiteModelAOptimizer:
         self.result = r
         kappa, omega0, omega2, p0, p1 = self._unpack(r.x)
         return kappa, omega0, omega2, p0, p1, float(-r.fun)
+
+
+class BranchModelOptimizer:
+    """optimize/branch.py -- two-ratio / multi-ratio (one omega per branch label) and free-ratio (one per branch) models.
+
+    Parameters: log kappa, log omega_j, log branch lengths.  As in the reference, the i-th branch-length parameter is
+    written to entry i of the boundary's branch-length vector (``branch_lengths[:-1] = optimized_lengths``, branch.py
+    ``compute_log_likelihood``) while its starting value is the length of the i-th non-root node of ``tree.postorder()``;
+    the two orders differ for most trees, which permutes the starting lengths but not the optimum.  The fitted lengths
+    are written back to the tree in the boundary's order, i.e. onto the nodes they were evaluated on."""
+
+    def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, free_ratio: bool = False,
+                 device: int = 0, batched_gradient: bool = True, engine=None):
+        if not optimize_branch_lengths:
+            raise NotImplementedError("Global branch scaling not yet implemented")     # as the reference
+        self.alignment, self.tree, self.use_f3x4, self.free_ratio = alignment, tree, use_f3x4, free_ratio
+        self.optimize_branch_lengths, self.batched_gradient = optimize_branch_lengths, batched_gradient
+        self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)
+        order = self.calc.postorder_nodes                                              # leaves first, then internals; root last
+        labels = np.array([int(tree.label[v]) if tree.parent[v] >= 0 else 0 for v in order])
+        self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]
+        self.n_branches = len(self.branch_nodes)
+        self.model = models.CodonBranchModel(self.pi, labels, free_ratio=free_ratio, n_nodes=len(order))
+        self._template = np.asarray(self.calc.branch_lengths_template, dtype=np.float64)
+        self.history = []
+        self.n_calls = self.n_vectors = 0
+
+    def negative_log_likelihoods(self, params):
+        params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        n_w = self.model.n_omega
+        if params.shape[1] != 1 + n_w + self.n_branches:
+            raise ValueError(f"Expected {self.n_branches} branch lengths, got {params.shape[1] - 1 - n_w}")
+        kappa = np.exp(params[:, 0])
+        omegas = np.exp(params[:, 1:1 + n_w])
+        bl = np.tile(self._template, (len(params), 1))
+        bl[:, :-1] = np.exp(params[:, 1 + n_w:])
+        lnl = np.asarray(self.calc.engine.codon_branch(kappa, np.ascontiguousarray(omegas[:, self.model.omega_labels]), self.pi, bl))
+        self.n_calls += 1
+        self.n_vectors += len(params)
+        self.history.append({"kappa": float(kappa[0]), "omega": {f"omega{i}": float(omegas[0, i]) for i in range(n_w)},
+                             "log_likelihood": float(lnl[0])})
+        return -lnl
+
+    def compute_log_likelihood(self, params):
+        return float(self.negative_log_likelihoods(np.asarray(params, dtype=np.float64)[None, :])[0])
+
+    def optimize(self, init_kappa: float = 3.0, init_omega: float = 0.4, method: str = "L-BFGS-B", maxiter: int = 500):
+        n_w = self.model.n_omega
+        x0 = np.array([np.log(init_kappa)] + [np.log(init_omega)] * n_w +
+                      [np.log(max(float(self.tree.branch_length[v]), 0.001)) for v in self.branch_nodes], dtype=np.float64)
+        bounds = [(np.log(0.1), np.log(999))] + [(np.log(1e-6), np.log(999))] * n_w + [(np.log(0.0001), np.log(50))] * self.n_branches
+        self.history = []
+        if self.batched_gradient and method == "L-BFGS-B":
+            r = minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bounds), x0, jac=True, method=method,
+                         bounds=bounds, options={"maxiter": maxiter, "disp": False})
+        else:
+            r = minimize(self.compute_log_likelihood, x0, method=method, bounds=bounds, options={"maxiter": maxiter, "disp": False})
+        self.result = r
+        omega = np.exp(r.x[1:1 + n_w])
+        self.tree.branch_length[np.array(self.calc.postorder_nodes[:-1])] = np.exp(r.x[1 + n_w:])
+        return float(np.exp(r.x[0])), {f"omega{i}": float(omega[i]) for i in range(n_w)}, float(-r.fun)

@@ -188,3 +188,31 @@ def test_branch_site_model_a_fit_against_paml():
     live = BranchSiteModelAOptimizer(aln4, tree4, live_branch_lengths=True)
     l_live = live.optimize(init_kappa=3.0, init_omega0=0.05, init_omega2=3.0, init_p0=0.35, init_p1=0.30, maxiter=500)[-1]
     assert abs(l_live - (-1035.533916)) < 0.2 and live.n_vectors == live.n_rows
+
+
+@pytest.mark.gpu
+def test_branch_model_fits_against_paml():
+    """tests/test_branch_paml_validation.py:25-122: the two-ratio model on lysozyme (PAML -903.076551, kappa 4.56831,
+    omega0 0.67535, omega1 at PAML's upper bound) with the reference test's tolerances, and the free-ratio model
+    (one omega per branch; nests M0 and the two-ratio model)."""
+    from crabml_amd.io import Alignment, Tree
+    from crabml_amd.optimize import BranchModelOptimizer
+    aln = Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"), seqtype="codon")
+    two = "((Hsa_Human,Hla_gibbon) #1, ((Cgu/Can_colobus,Pne_langur), Mmu_rhesus), (Ssc_squirrelM,Cja_marmoset));"
+    tree = Tree.from_newick(two)
+    opt = BranchModelOptimizer(aln, tree, use_f3x4=True, optimize_branch_lengths=True, free_ratio=False)
+    kappa, omega, lnl = opt.optimize(init_kappa=3.0, init_omega=0.4, method="L-BFGS-B", maxiter=1000)
+    assert abs(lnl - (-903.076551)) < 0.5 and abs(kappa - 4.56831) < 0.1 and abs(omega["omega0"] - 0.67535) < 0.05
+    assert omega["omega1"] > 5.0 and set(omega) == {"omega0", "omega1"}
+    assert opt.n_vectors == opt.n_calls * (1 + 2 + 11 + 1)
+    # the fitted lengths sit on the nodes they were evaluated on: re-evaluating from the tree reproduces the optimum
+    again = BranchModelOptimizer(aln, tree, free_ratio=False)
+    x = np.concatenate([opt.result.x[:3], np.log(tree.branch_length[np.array(again.calc.postorder_nodes[:-1])])])
+    assert abs(-again.compute_log_likelihood(x) - lnl) < 1e-9
+    seq = BranchModelOptimizer(aln, Tree.from_newick(two), batched_gradient=False)
+    assert seq.optimize(init_kappa=3.0, init_omega=0.4, maxiter=1000) == (kappa, omega, lnl)
+    free = BranchModelOptimizer(aln, Tree.from_newick(two), free_ratio=True)
+    k_f, omega_f, l_f = free.optimize(maxiter=500)
+    assert len(omega_f) == 11 and l_f >= lnl - 0.05 and l_f >= -906.017440 and 2.0 < k_f < 10.0
+    with pytest.raises(NotImplementedError):
+        BranchModelOptimizer(aln, Tree.from_newick(two), optimize_branch_lengths=False)
