@@ -163,3 +163,21 @@ def make_case(model: str, n_taxa: int, n_sites: int, seed: int, mean_branch: flo
     else:
         raise ValueError(f"unknown model {model}")
     return case
+
+
+def as_alignment_and_tree(case):
+    """(Alignment, Tree) objects for a synthetic case: what the adapter and the optimiser mirrors take."""
+    from .io import Alignment, Tree
+    parent = np.asarray(case.parent)
+    kids = [[] for _ in parent]
+    for v, p in enumerate(parent):
+        if p >= 0:
+            kids[p].append(v)
+    leaf_name = {int(v): f"t{i}" for i, v in enumerate(case.leaf_node_ids)}
+
+    def newick(v):
+        s = leaf_name[v] if not kids[v] else "(" + ",".join(newick(c) for c in kids[v]) + ")"
+        return s + (f":{float(case.branch_lengths[v])!r}" if parent[v] >= 0 else "")
+
+    root = int(np.flatnonzero(parent < 0)[0])
+    return Alignment.from_codes([leaf_name[int(v)] for v in case.leaf_node_ids], case.codes), Tree.from_newick(newick(root) + ";")

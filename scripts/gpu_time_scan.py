@@ -10,29 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np   # noqa: E402
 
 from crabml_amd import scan, synth   # noqa: E402
-from crabml_amd.io import Alignment, Tree   # noqa: E402
 
 n_genes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 
 
-def as_inputs(case):
-    parent = np.asarray(case.parent)
-    kids = [[] for _ in parent]
-    for v, p in enumerate(parent):
-        if p >= 0:
-            kids[p].append(v)
-    leaf_name = {int(v): f"t{i}" for i, v in enumerate(case.leaf_node_ids)}
-
-    def newick(v):
-        s = leaf_name[v] if not kids[v] else "(" + ",".join(newick(c) for c in kids[v]) + ")"
-        return s + (f":{float(case.branch_lengths[v])!r}" if parent[v] >= 0 else "")
-
-    root = int(np.flatnonzero(parent < 0)[0])
-    return Alignment.from_codes([leaf_name[int(v)] for v in case.leaf_node_ids], case.codes), Tree.from_newick(newick(root) + ";")
-
-
-genes = [as_inputs(synth.make_case("M8", 30, 400, seed=2000 + g)) for g in range(n_genes)]
+genes = [synth.as_alignment_and_tree(synth.make_case("M8", 30, 400, seed=2000 + g)) for g in range(n_genes)]
 scan.scan(genes[:2], workers=2)   # first use of the device and of scipy's code paths
 for w in (1, workers):
     t0 = time.perf_counter()
