@@ -125,9 +125,10 @@ class _SiteClassOptimizer:
         if not self.optimize_branch_lengths:
             return [np.log(1.0)], [(np.log(0.01), np.log(100))]
         init = [float(self.tree.branch_length[v]) for v in self.branch_nodes]
-        if max(init) < 0.001:
-            raise ValueError("the tree has no branch lengths; the reference's least-squares initialisation "
-                             "(optimize/distance_init.py) is outside this path -- give starting lengths")
+        if max(init) < 0.001 and isinstance(self, M0Optimizer):          # optimizer.py:170-188: only M0 has the fallback
+            from .distance_init import initialize_branch_lengths_ls
+            init = [float(b) for b in initialize_branch_lengths_ls(self.alignment, self.tree, self.branch_nodes)]
+            self.tree.branch_length[np.array(self.branch_nodes)] = init
         return [np.log(max(b, 0.001)) for b in init], [(np.log(0.0001), np.log(50))] * self.n_branches
 
     def _minimize(self, init_model, method, maxiter):

@@ -216,3 +216,44 @@ def test_branch_model_fits_against_paml():
     assert len(omega_f) == 11 and l_f >= lnl - 0.05 and l_f >= -906.017440 and 2.0 < k_f < 10.0
     with pytest.raises(NotImplementedError):
         BranchModelOptimizer(aln, Tree.from_newick(two), optimize_branch_lengths=False)
+
+
+def _lysin():
+    from crabml_amd.io import Alignment, Tree
+    aln = Alignment.from_fasta(os.path.join(DATA, "lysin.fasta"), seqtype="codon")
+    lines = [ln.strip() for ln in open(os.path.join(DATA, "lysin.trees")) if ln.strip()]
+    text = "".join(ln for ln in lines[1:] if not ln.startswith("#")).replace(": ", ":").replace(" #1", "")   # test_lysin.py:65-74
+    return aln, Tree.from_newick(text)
+
+
+def test_least_squares_starting_lengths_match_the_reference():
+    """optimize/distance_init.py on the lysin example (a tree without branch lengths), against the reference's own output
+    (tests/golden/make_golden_distance_init.py).  Distances are exact; the lengths come out of an L-BFGS-B run that the
+    reference stops at ftol = 1e-4, so they are a starting point and agree to the optimiser's own accuracy."""
+    from crabml_amd.distance_init import compute_pairwise_distances, initialize_branch_lengths_ls, path_incidence
+    from util import load_case
+    c = load_case("lysin_distance_init")
+    aln, tree = _lysin()
+    np.testing.assert_array_equal(compute_pairwise_distances(aln), c["pairwise"])
+    branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]
+    assert [tree.name[v] or "" for v in branch_nodes] == [str(s) for s in c["branch_node_names"]]
+    A = path_incidence(tree, branch_nodes)
+    assert A.shape == (25 * 24 // 2, 47) and A.sum(axis=1).min() >= 2          # every pair is joined through at least two branches
+    b = initialize_branch_lengths_ls(aln, tree, branch_nodes)
+    np.testing.assert_allclose(b, c["branch_lengths"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_lysin_fits_from_a_tree_without_branch_lengths():
+    """tests/test_paml_examples/test_lysin.py:83-154 -- 25 abalone sperm lysin sequences with alignment gaps, topology
+    only: least-squares starting lengths, then M0 / M1a / M2a to within 0.01 of PAML's lnL, as the reference asks."""
+    from crabml_amd.optimize import M0Optimizer, M1aOptimizer, M2aOptimizer
+    aln, tree = _lysin()
+    _, _, l0 = M0Optimizer(aln, tree, use_f3x4=True).optimize(maxiter=1000)
+    assert abs(l0 - (-4682.373100)) < 0.01
+    aln, tree = _lysin()
+    *_, l1 = M1aOptimizer(aln, tree, use_f3x4=True).optimize(maxiter=1000)
+    assert abs(l1 - (-4525.413236)) < 0.01
+    aln, tree = _lysin()
+    *_, l2 = M2aOptimizer(aln, tree, use_f3x4=True).optimize(maxiter=1000)
+    assert abs(l2 - (-4464.511376)) < 0.01
