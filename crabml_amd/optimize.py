@@ -1,7 +1,8 @@
 """Maximum-likelihood fits with the whole finite-difference gradient in one call.
 
 Mirror of the reference's optimisers for the site-class models (src/crabml/optimize/optimizer.py: M0Optimizer :24-249,
-M1aOptimizer :252-408, M2aOptimizer :411-601, M7Optimizer :867-1029, M8Optimizer :1032-1218, M8aOptimizer :1221-1412;
+M1aOptimizer :252-408, M2aOptimizer :411-601, M3Optimizer :604-864, M7Optimizer :867-1029, M8Optimizer :1032-1218,
+M8aOptimizer :1221-1412, M5/M9/M4/M6Optimizer :1415-2100;
 src/crabml/optimize/branch_site.py: BranchSiteModelAOptimizer; src/crabml/optimize/branch.py: BranchModelOptimizer): same parameter transforms, bounds, starting values and return values,
 same ``scipy.optimize.minimize(method='L-BFGS-B')`` driver.  The difference is where the gradient comes from.  The
 reference passes no ``jac``, so scipy differentiates numerically: n + 1 sequential calls through the FFI per gradient
@@ -433,3 +434,184 @@ class BranchModelOptimizer:
         omega = np.exp(r.x[1:1 + n_w])
         self.tree.branch_length[np.array(self.calc.postorder_nodes[:-1])] = np.exp(r.x[1 + n_w:])
         return float(np.exp(r.x[0])), {f"omega{i}": float(omega[i]) for i in range(n_w)}, float(-r.fun)
+
+
+class _NoM0Start(_SiteClassOptimizer):
+    """M4, M5, M6 and M9 of the reference take no ``init_with_m0`` (optimizer.py:1415-2100): they start from the tree as given."""
+
+    def __init__(self, alignment, tree, ncatG: int = 10, use_f3x4: bool = True, optimize_branch_lengths: bool = True, **kw):
+        kw.pop("init_with_m0", None)
+        super().__init__(alignment, tree, use_f3x4=use_f3x4, optimize_branch_lengths=optimize_branch_lengths, init_with_m0=False, **kw)
+        self.ncatG = ncatG
+
+
+class M5Optimizer(_NoM0Start):
+    """optimizer.py:1415-1557: omega ~ Gamma(alpha, beta), ``ncatG`` median quantiles."""
+    n_model = 3
+    model_bounds = [(np.log(0.1), np.log(100)), _BETA_BOUND, _BETA_BOUND]
+
+    def model_at(self, p):
+        return models.M5CodonModel(kappa=float(np.exp(p[0])), alpha=float(np.exp(p[1])), beta=float(np.exp(p[2])), ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "alpha": m.alpha, "beta": m.beta, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_alpha: float = 1.0, init_beta: float = 1.0, method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_alpha), np.log(init_beta)], method, maxiter)
+        return float(np.exp(r.x[0])), float(np.exp(r.x[1])), float(np.exp(r.x[2])), float(-r.fun)
+
+
+class M9Optimizer(_NoM0Start):
+    """optimizer.py:1560-1732: omega ~ p0 Beta(p, q) + (1 - p0) Gamma(alpha, beta)."""
+    n_model = 6
+    model_bounds = [(np.log(0.1), np.log(100)), (-10, 10), _BETA_BOUND, _BETA_BOUND, _BETA_BOUND, _BETA_BOUND]
+
+    def model_at(self, p):
+        return models.M9CodonModel(kappa=float(np.exp(p[0])), p0=float(_sigmoid(p[1])), p_beta=float(np.exp(p[2])), q_beta=float(np.exp(p[3])),
+                                   alpha=float(np.exp(p[4])), beta_gamma=float(np.exp(p[5])), ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "p0": m.p0, "p_beta": m.p_beta, "q_beta": m.q_beta, "alpha": m.alpha, "beta_gamma": m.beta_gamma,
+                "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_p0: float = 0.5, init_p_beta: float = 0.5, init_q_beta: float = 0.5,
+                 init_alpha: float = 1.0, init_beta_gamma: float = 1.0, method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_p0 / (1 - init_p0)), np.log(init_p_beta), np.log(init_q_beta),
+                                          np.log(init_alpha), np.log(init_beta_gamma)], method, maxiter)
+        return (float(np.exp(r.x[0])), float(_sigmoid(r.x[1])), float(np.exp(r.x[2])), float(np.exp(r.x[3])), float(np.exp(r.x[4])),
+                float(np.exp(r.x[5])), float(-r.fun))
+
+
+class M6Optimizer(_NoM0Start):
+    """optimizer.py:1899-2100: omega ~ p0 Gamma(alpha1, beta1) + (1 - p0) Gamma(alpha2, alpha2)."""
+    n_model = 5
+    model_bounds = [(np.log(0.1), np.log(100)), (-10, 10), _BETA_BOUND, _BETA_BOUND, _BETA_BOUND]
+
+    def model_at(self, p):
+        return models.M6CodonModel(kappa=float(np.exp(p[0])), p0=float(_sigmoid(p[1])), alpha1=float(np.exp(p[2])), beta1=float(np.exp(p[3])),
+                                   alpha2=float(np.exp(p[4])), ncatG=self.ncatG, pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "p0": m.p0, "alpha1": m.alpha1, "beta1": m.beta1, "alpha2": m.alpha2, "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_p0: float = 0.5, init_alpha1: float = 1.0, init_beta1: float = 1.0,
+                 init_alpha2: float = 1.0, method: str = "L-BFGS-B", maxiter: int = 200):
+        self.result = r = self._minimize([np.log(init_kappa), np.log(init_p0 / (1 - init_p0)), np.log(init_alpha1), np.log(init_beta1),
+                                          np.log(init_alpha2)], method, maxiter)
+        return (float(np.exp(r.x[0])), float(_sigmoid(r.x[1])), float(np.exp(r.x[2])), float(np.exp(r.x[3])), float(np.exp(r.x[4])),
+                float(-r.fun))
+
+
+class M4Optimizer(_NoM0Start):
+    """optimizer.py:1735-1896: five fixed omegas (0, 1/3, 2/3, 1, 3), free proportions as a softmax over four logits and 1."""
+    n_model = 5
+    model_bounds = [(np.log(0.1), np.log(100))] + [(-10, 10)] * 4
+
+    def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, **kw):
+        super().__init__(alignment, tree, use_f3x4=use_f3x4, optimize_branch_lengths=optimize_branch_lengths, **kw)
+
+    @staticmethod
+    def _proportions(logits):
+        raw = np.concatenate([np.exp(logits - np.max(logits)), [1.0]])                 # optimizer.py:1782-1785
+        return raw / raw.sum()
+
+    def model_at(self, p):
+        return models.M4CodonModel(kappa=float(np.exp(p[0])), proportions=self._proportions(p[1:5]).tolist(), pi=self.pi)
+
+    def record(self, m, lnl):
+        return {"kappa": m.kappa, "proportions": list(m.get_site_classes()[0]), "log_likelihood": lnl}
+
+    def optimize(self, init_kappa: float = 2.0, init_proportions=None, method: str = "L-BFGS-B", maxiter: int = 200):
+        if init_proportions is None:
+            init_proportions = [0.2, 0.2, 0.2, 0.2, 0.2]
+        else:
+            if len(init_proportions) != 5:
+                raise ValueError("M4 requires exactly 5 initial proportions")
+            init_proportions = np.array(init_proportions, dtype=np.float64)
+            init_proportions = init_proportions / init_proportions.sum()
+        self.result = r = self._minimize([np.log(init_kappa)] + np.log(init_proportions[:4]).tolist(), method, maxiter)
+        return float(np.exp(r.x[0])), self._proportions(r.x[1:5]).tolist(), float(-r.fun)
+
+
+class M3Optimizer(_SiteClassOptimizer):
+    """optimizer.py:604-864: K free omegas and proportions in PAML's layout -- kappa and the omegas on their natural scale,
+    proportions as f_k = e^{x_k} / (1 + sum e^{x_j}) with the last class as the reference, starting values from PAML's
+    GetInitialsCodon formulas with ``numpy.random.default_rng(seed=trial)`` in place of rndu(), tight stopping rule."""
+
+    def __init__(self, alignment, tree, n_classes: int = 3, **kw):
+        super().__init__(alignment, tree, **kw)
+        self.n_classes = n_classes
+        self.n_model = 1 + (n_classes - 1) + n_classes
+
+    @staticmethod
+    def _f_and_x(logits):
+        e = np.exp(np.asarray(logits, dtype=float))
+        denom = 1.0 + np.sum(e)
+        return np.append(e / denom, 1.0 / denom)
+
+    def model_at(self, p):
+        K = self.n_classes
+        return models.M3CodonModel(kappa=float(p[0]), omegas=[float(w) for w in p[K:2 * K]], proportions=self._f_and_x(p[1:K]).tolist(),
+                                   pi=self.pi)
+
+    def record(self, m, lnl):
+        props, omegas = m.get_site_classes()
+        return {"kappa": m.kappa, "omegas": list(omegas), "proportions": list(props), "log_likelihood": lnl}
+
+    def _build_bounds(self, K):
+        return [(1e-4, 999.0)] + [(-99.0, 99.0)] * (K - 1) + [(1e-6, 999.0)] * K + \
+            ([(np.log(0.0001), np.log(50))] * self.n_branches if self.optimize_branch_lengths else [(np.log(0.01), np.log(100))])
+
+    def _build_init_params(self, K, kappa, omega, rng=None):
+        rndu = rng.random if rng is not None else (lambda: 0.5)
+        kappa_init = 0.1 + kappa * (0.8 + 0.4 * rndu())
+        logits = [rndu() for _ in range(K - 1)]
+        omegas = [max(omega * (0.5 + i * 2.0 / K * (0.8 + 0.4 * rndu())), 1e-4) for i in range(K)]
+        tail = ([np.log(max(float(self.tree.branch_length[v]), 0.001)) for v in self.branch_nodes] if self.optimize_branch_lengths
+                else [np.log(1.0)])
+        return np.array([kappa_init] + logits + omegas + tail), kappa_init, omegas, logits
+
+    @staticmethod
+    def _enforce_bounds(params, bounds):
+        for i, (lo, hi) in enumerate(bounds):
+            if params[i] < lo * 1.005:
+                params[i] = lo * 1.05
+            if params[i] > hi / 1.005:
+                params[i] = hi / 1.05
+
+    def _extract_result(self, x, K):
+        props, omegas = self._f_and_x(x[1:K]).tolist(), x[K:2 * K].tolist()
+        order = np.argsort(omegas)                                                     # PAML's sortwM3
+        return float(x[0]), [omegas[i] for i in order], [props[i] for i in order]
+
+    def optimize(self, init_kappa: float = 2.0, init_omegas=None, init_proportions=None, method: str = "L-BFGS-B", maxiter: int = 500,
+                 n_restarts: int = 1):
+        m0_omega = 2.1
+        if self.init_with_m0 and self.optimize_branch_lengths:
+            m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
+                             batched_gradient=self.batched_gradient, engine=self.engine)
+            init_kappa, m0_omega, _ = m0.optimize()
+            self.n_calls += m0.n_calls
+            self.n_vectors += m0.n_vectors
+        K = self.n_classes
+        bounds = self._build_bounds(K)
+        nodes = np.array(self.branch_nodes)
+        start_lengths = self.tree.branch_length[nodes].copy()
+        best = (-np.inf, None, None, None)
+        options = {"maxiter": maxiter, "ftol": 1e-15, "gtol": 1e-10}
+        for trial in range(n_restarts):
+            self.tree.branch_length[nodes] = start_lengths
+            x0, *_ = self._build_init_params(K, init_kappa, m0_omega, rng=np.random.default_rng(seed=trial))
+            self._enforce_bounds(x0, bounds)
+            self.history = []
+            if self.batched_gradient and method == "L-BFGS-B":
+                r = minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bounds), x0, jac=True, method=method,
+                             bounds=bounds, options=options)
+            else:
+                r = minimize(self.compute_log_likelihood, x0, method=method, bounds=bounds, options=options)
+            if -r.fun > best[0]:
+                best = (float(-r.fun), self._extract_result(r.x, K), self.tree.branch_length[nodes].copy(), r)
+        self.tree.branch_length[nodes] = best[2]
+        self.result = best[3]
+        kappa, omegas, props = best[1]
+        return kappa, omegas, props, best[0]

@@ -257,3 +257,47 @@ def test_lysin_fits_from_a_tree_without_branch_lengths():
     aln, tree = _lysin()
     *_, l2 = M2aOptimizer(aln, tree, use_f3x4=True).optimize(maxiter=1000)
     assert abs(l2 - (-4464.511376)) < 0.01
+
+
+@pytest.mark.gpu
+def test_m4_m5_m6_m9_fits_reach_pamls_optima():
+    """The remaining site-class optimisers (optimizer.py:1415-2100; none of them takes an M0 start) on lysozyme, against
+    the likelihoods PAML reports at its optima (tests/test_rust/test_paml_rust_validation.py:569,627,689,745)."""
+    from crabml_amd.optimize import M4Optimizer, M5Optimizer, M6Optimizer, M9Optimizer
+    paml = {M5Optimizer: -900.222360, M9Optimizer: -899.997270, M4Optimizer: -900.139530, M6Optimizer: -900.167515}
+    for cls, want in paml.items():
+        aln, tree = _lysozyme()
+        opt = cls(aln, tree)
+        out = opt.optimize(maxiter=500)
+        # M4's optimum has two proportions at zero, i.e. logits at the -10 bound: the driver stops 0.3 short of it from this start
+        assert abs(out[-1] - want) < (0.5 if cls is M4Optimizer else 0.05), (cls.__name__, out[-1], want)
+        assert out[-1] <= want + 0.01
+        assert opt.n_vectors == opt.n_calls * (cls.n_model + 11 + 1)
+    kappa, props, _ = out if cls is M4Optimizer else M4Optimizer(*_lysozyme()).optimize(maxiter=5)
+    assert len(props) == 5 and abs(sum(props) - 1.0) < 1e-12 and kappa > 0
+    with pytest.raises(ValueError, match="exactly 5"):
+        M4Optimizer(*_lysozyme()).optimize(init_proportions=[0.5, 0.5])
+
+
+@pytest.mark.gpu
+def test_m3_fit_reaches_pamls_optimum():
+    """optimizer.py:604-864 on lysozyme: PAML's M3 (K = 3) optimum is -899.985262
+    (tests/test_rust/test_paml_rust_validation.py:223); omegas come back sorted with their proportions (sortwM3)."""
+    from crabml_amd.optimize import M3Optimizer
+    aln, tree = _lysozyme()
+    opt = M3Optimizer(aln, tree, n_classes=3)
+    kappa, omegas, props, lnl = opt.optimize()
+    assert abs(lnl - (-899.985262)) < 0.05 and lnl <= -899.985262 + 0.01
+    assert omegas == sorted(omegas) and len(omegas) == len(props) == 3 and abs(sum(props) - 1.0) < 1e-12 and kappa > 0
+    aln, tree = _lysozyme()
+    two = M3Optimizer(aln, tree, n_classes=3)
+    *_, best = two.optimize(n_restarts=2, maxiter=200)
+    assert best >= lnl - 0.05
+    # PAML's starting values with rndu() = 0.5, and SetxInitials pushing values off the bounds
+    x0, k0, w0, l0 = opt._build_init_params(3, 2.0, 0.4)
+    assert k0 == 0.1 + 2.0 and l0 == [0.5, 0.5] and np.allclose(w0, [0.4 * 0.5, 0.4 * (0.5 + 2 / 3), 0.4 * (0.5 + 4 / 3)])
+    b = opt._build_bounds(3)
+    assert len(b) == len(x0) == 1 + 2 + 3 + 11 and b[0] == (1e-4, 999.0) and b[1] == (-99.0, 99.0) and b[3] == (1e-6, 999.0)
+    p = np.array([1e-4, 0.0, 1000.0])
+    M3Optimizer._enforce_bounds(p, [(1e-4, 999.0), (-99.0, 99.0), (1e-6, 999.0)])
+    assert p[0] == 1e-4 * 1.05 and p[1] == 0.0 and p[2] == 999.0 / 1.05
