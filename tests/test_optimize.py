@@ -301,3 +301,21 @@ def test_m3_fit_reaches_pamls_optimum():
     p = np.array([1e-4, 0.0, 1000.0])
     M3Optimizer._enforce_bounds(p, [(1e-4, 999.0), (-99.0, 99.0), (1e-6, 999.0)])
     assert p[0] == 1e-4 * 1.05 and p[1] == 0.0 and p[2] == 999.0 / 1.05
+
+
+@pytest.mark.gpu
+def test_hiv_nssites_fits_against_paml():
+    """tests/test_paml_examples/test_hiv_nssites.py:76-230 -- PAML's HIV-1 env example (13 sequences, 91 codons), the six
+    site models the reference checks, each to within 0.01 of PAML's lnL with the default starting values."""
+    from crabml_amd.io import Alignment, Tree
+    from crabml_amd import optimize as O
+    lines = [ln.strip() for ln in open(os.path.join(DATA, "HIVenvSweden.trees")) if ln.strip()]
+    text = lines[1].replace(": ", ":")
+    paml = {"M0": -1137.688190, "M1a": -1114.641736, "M2a": -1106.445004, "M7": -1115.395312, "M8": -1106.388268, "M8a": -1114.579213}
+    got = {}
+    for name, want in paml.items():
+        aln = Alignment.from_fasta(os.path.join(DATA, "HIVenvSweden.fasta"), seqtype="codon")
+        out = getattr(O, name + "Optimizer")(aln, Tree.from_newick(text), use_f3x4=True).optimize()
+        got[name] = out[-1]
+        assert abs(out[-1] - want) < 0.01, (name, out[-1], want)
+    assert got["M0"] < got["M1a"] < got["M2a"] and got["M7"] < got["M8"] and got["M8a"] < got["M8"]
