@@ -319,3 +319,46 @@ def test_hiv_nssites_fits_against_paml():
         got[name] = out[-1]
         assert abs(out[-1] - want) < 0.01, (name, out[-1], want)
     assert got["M0"] < got["M1a"] < got["M2a"] and got["M7"] < got["M8"] and got["M8a"] < got["M8"]
+
+
+def test_api_loaders_and_model_names():
+    """api.py:908-1018, 1156-1165: format detection by suffix with the other format as fallback, a Newick string or a
+    file for the tree, objects passed through, and the error for an unknown model name (raised before any device work)."""
+    from crabml_amd import api
+    from crabml_amd.io import Alignment, Tree
+    aln = api._load_alignment(os.path.join(DATA, "lysozymeSmall.txt"))
+    assert (aln.n_species, aln.n_sites) == (7, 130) and api._load_alignment(aln) is aln
+    assert api._load_alignment(os.path.join(DATA, "lysin.fasta")).n_species == 25
+    assert api._load_alignment(os.path.join(DATA, "lysozymeLarge_clean.nuc")).n_species == 19      # unknown suffix: FASTA fails, PHYLIP reads it
+    with pytest.raises(FileNotFoundError):
+        api._load_alignment(os.path.join(DATA, "no_such_file.fasta"))
+    t = api._load_tree(LYSOZYME_START)
+    assert t.n_leaves == 7 and api._load_tree(t) is t
+    assert api._load_tree(os.path.join(DATA, "lysozymeLarge.trees")).n_leaves == 19
+    with pytest.raises(ValueError, match="Failed to parse tree"):
+        api._load_tree("((a,b")
+    with pytest.raises(ValueError, match="Unknown model: 'M99'"):
+        api.optimize_model("M99", aln, t)
+
+
+@pytest.mark.gpu
+def test_optimize_model_and_the_tests_for_positive_selection():
+    """BASELINE configs[0]: ``optimize_model("M0", ...)`` on the bundled lysozyme files, by path; parameter names and
+    counts as api.py:615-837 reports them (PAML's np = 13 for M0 on this tree); the M7-M8 and M8a-M8 tests."""
+    from scipy.stats import chi2
+    from crabml_amd import api
+    res = api.optimize_model("m0", os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
+    assert res.model_name == "M0" and abs(res.lnL - (-906.017440)) < 1e-3 and abs(res.omega - 0.80663) < 5e-3 and res.n_params == 13
+    assert set(res.params) == {"omega"} and res.to_dict()["tree"].count(":") == 11 and res.convergence_info["iterations"] > 0
+    m2 = api.optimize_model("M2a", os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START, maxiter=300)
+    assert set(m2.params) == {"p0", "p1", "p2", "omega0", "omega2"} and m2.n_params == 16 and m2.omega is None
+    assert abs(m2.params["p0"] + m2.params["p1"] + m2.params["p2"] - 1.0) < 1e-12 and abs(m2.lnL - (-899.998568)) < 2e-2
+    m3 = api.optimize_model("M3", os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START, n_classes=2, init_with_m0=False)
+    assert len(m3.params["omegas"]) == 2 and m3.n_params == 1 + 1 + 2 + 11
+    t78 = api.m7_vs_m8(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
+    assert abs(t78["LRT"] - 2 * (-899.999237 + 902.510018)) < 0.1 and t78["df"] == 2 and t78["pvalue"] == chi2.sf(t78["LRT"], 2)
+    assert set(t78["alternative"].params) == {"p0", "p", "q", "omega_s"} and set(t78["null"].params) == {"p", "q"}
+    t8a = api.m8a_vs_m8(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
+    assert t8a["pvalue"] == 0.5 * chi2.sf(t8a["LRT"], 1) and t8a["null"].params["omega_s"] == 1.0 and t8a["null"].n_params == 15
+    t12 = api.m1a_vs_m2a(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
+    assert abs(t12["LRT"] - 2 * (-899.998568 + 902.503872)) < 0.1
