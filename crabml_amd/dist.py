@@ -46,6 +46,26 @@ def ordered_sum(partial: float, group=None, device=None) -> float:
     return total
 
 
+def ordered_sum_vector(partials, group=None, device=None):
+    """``ordered_sum`` for a vector: the B partial log-likelihoods of a batched evaluation (a point and its
+    finite-difference neighbours) in ONE all-gather, summed in rank order on every rank."""
+    import torch
+    import torch.distributed as dist
+    partials = np.asarray(partials, dtype=np.float64)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return partials
+    ws = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.from_numpy(np.ascontiguousarray(partials)).to(device)
+    parts = [torch.empty_like(mine) for _ in range(ws)]
+    dist.all_gather(parts, mine, group=group)
+    total = np.zeros_like(partials)
+    for part in parts:
+        total = total + part.cpu().numpy()
+    return total
+
+
 class ShardedLikelihood:
     """Wraps a per-rank evaluator ``evaluate(*args, **kw) -> partial lnL over this rank's patterns``."""
 

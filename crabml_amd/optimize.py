@@ -68,12 +68,17 @@ class _SiteClassOptimizer:
     model_bounds: list = []
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, init_with_m0: bool = True,
-                 device: int = 0, batched_gradient: bool = True, engine=None):
+                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None):
         self.alignment, self.tree = alignment, tree
         self.init_with_m0, self.device, self.engine = init_with_m0, device, engine
+        self.rank, self.world_size, self.group = rank, world_size, group
         self.use_f3x4, self.optimize_branch_lengths = use_f3x4, optimize_branch_lengths
         self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
-        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)   # engine: one to re-target, e.g. a scan worker's
+        # engine: one to re-target, e.g. a scan worker's.  world_size > 1: this rank's engine holds its slice of the site
+        # patterns and every likelihood below is the rank-ordered sum of the ranks' partial sums (one all-gather per
+        # gradient), so all ranks see the same bits and walk the same path.
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine,
+                                             pattern_slice=self._pattern_slice(alignment, rank, world_size))
         self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]          # optimizer.py:72
         self.n_branches = len(self.branch_nodes)
         self._branch_rows = np.array([self.calc.node_id_map[v] for v in self.branch_nodes])
@@ -81,6 +86,15 @@ class _SiteClassOptimizer:
         self.history = []
         self.n_calls = 0            # calls through the C ABI
         self.n_vectors = 0          # parameter vectors evaluated
+
+    @staticmethod
+    def _pattern_slice(alignment, rank, world_size):
+        if world_size == 1:
+            return None
+        from .dist import pattern_slices
+        from .engine import compress_patterns
+        n_patterns = len(compress_patterns(np.ascontiguousarray(alignment.sequences, dtype=np.int32))[1])
+        return pattern_slices(n_patterns, world_size)[rank]
 
     # -- model specifics, per subclass ---------------------------------------------------------
     def model_at(self, p):          # p: the leading n_model entries of a parameter vector
@@ -112,6 +126,9 @@ class _SiteClassOptimizer:
                                                   np.array([c[0] for c in cls], dtype=np.float64)[row_model], self.pi,
                                                   self._branch_lengths(params))
         classes = [distinct[row_model[0]]]
+        if self.world_size > 1:
+            from .dist import ordered_sum_vector
+            lnl = ordered_sum_vector(lnl, self.group)
         self.n_calls += 1
         self.n_vectors += len(params)
         if self.optimize_branch_lengths:                                   # the reference leaves the last values in the tree
@@ -135,7 +152,8 @@ class _SiteClassOptimizer:
     def _minimize(self, init_model, method, maxiter):
         if self.init_with_m0 and self.optimize_branch_lengths and not isinstance(self, M0Optimizer):   # optimizer.py:346-355
             m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
-                             batched_gradient=self.batched_gradient, engine=self.engine)
+                             batched_gradient=self.batched_gradient, engine=self.engine, rank=self.rank, world_size=self.world_size,
+                             group=self.group)
             m0.optimize()
             self.n_calls += m0.n_calls
             self.n_vectors += m0.n_vectors
@@ -589,7 +607,8 @@ class M3Optimizer(_SiteClassOptimizer):
         m0_omega = 2.1
         if self.init_with_m0 and self.optimize_branch_lengths:
             m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
-                             batched_gradient=self.batched_gradient, engine=self.engine)
+                             batched_gradient=self.batched_gradient, engine=self.engine, rank=self.rank, world_size=self.world_size,
+                             group=self.group)
             init_kappa, m0_omega, _ = m0.optimize()
             self.n_calls += m0.n_calls
             self.n_vectors += m0.n_vectors

@@ -191,8 +191,12 @@ class _OracleEngine:
     def set_tree_structure(self, tree_structure, leaf_node_ids):
         self.ts, self.leaf = list(tree_structure), list(leaf_node_ids)
 
-    def set_alignment(self, codes, **_):
-        self.codes = np.asarray(codes)
+    def set_alignment(self, codes, pattern_begin=0, pattern_end=-1, **_):
+        from crabml_amd.engine import compress_patterns
+        codes = np.ascontiguousarray(codes, dtype=np.int32)
+        _, w, first = compress_patterns(codes)                       # the engine's own pattern order
+        end = len(w) if pattern_end < 0 else pattern_end
+        self.codes, self.weights = np.ascontiguousarray(codes[:, first[pattern_begin:end]]), w[pattern_begin:end]
 
     def codon_site_classes(self, kappa, omegas, proportions, pi, branch_lengths, no_clamp=False):
         from crabml_amd import models
@@ -201,8 +205,12 @@ class _OracleEngine:
         for k, om, pr, bl in zip(kappa, omegas, proportions, branch_lengths):
             raw = [models.build_codon_Q_matrix(float(k), float(w), pi, 1.0) for w in om]
             scale = sum(p * models.mean_rate(Q, pi) for p, Q in zip(pr, raw))
-            out.append(orc.compute_site_class_log_likelihood([Q / scale for Q in raw], pr, pi, self.ts, bl, None, self.codes, self.leaf,
-                                                             threads=1))
+            if self.codes.shape[1] == 0:
+                out.append(0.0)
+                continue
+            site = orc.compute_site_class_log_likelihood([Q / scale for Q in raw], pr, pi, self.ts, bl, None, self.codes, self.leaf,
+                                                         threads=1, return_sites=True)[1]
+            out.append(float(self.weights @ site))
         return np.array(out)
 
     def close(self):
@@ -262,3 +270,41 @@ def test_lrt_statistics_follow_the_reference():
         assert calculate_lrt(-10.0, -10.5, 2) == (0.0, 1.0)
     with pytest.warns(UserWarning, match="Negative LRT"):
         assert calculate_lrt_mixture(-10.0, -10.5, 1) == (0.0, 1.0)
+
+
+def _fit_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from crabml_amd import synth
+        from crabml_amd.optimize import M2aOptimizer
+        aln, tree = synth.as_alignment_and_tree(synth.make_case("M8", 5, 400, seed=11))
+        opt = M2aOptimizer(aln, tree, engine=_OracleEngine(), rank=rank, world_size=world)
+        res = opt.optimize(maxiter=2)
+        out[rank] = (res, opt.result.x.tolist(), opt.calc.engine.codes.shape[1], opt.n_calls)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_fit_over_pattern_slices_equals_the_single_rank_fit():
+    """A fit with the site patterns sharded over ranks: every likelihood of every stencil is the rank-ordered sum of
+    partial sums (one all-gather of B doubles per gradient, north_star's "lnL and finite-difference gradient components"),
+    so both ranks hold identical iterates, and they are the single-rank fit's up to the summation order."""
+    from crabml_amd import synth
+    from crabml_amd.optimize import M2aOptimizer
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fit_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = [out[r] for r in range(world)]
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][3] == res[1][3]      # same bits on both ranks
+    assert res[0][2] % 128 == 0 and res[0][2] > 0 and res[1][2] > 0                                               # both ranks held patterns
+    aln, tree = synth.as_alignment_and_tree(synth.make_case("M8", 5, 400, seed=11))
+    alone = M2aOptimizer(aln, tree, engine=_OracleEngine())
+    want = alone.optimize(maxiter=2)
+    assert alone.calc.engine.codes.shape[1] == res[0][2] + res[1][2]
+    # a different summation order moves f by ~1e-13, the 1e-8-step gradient by ~1e-5, and the iterates with it
+    np.testing.assert_allclose(res[0][0], want, rtol=1e-3)
+    assert abs(res[0][0][-1] - want[-1]) < 1e-6 * abs(want[-1])

@@ -1065,3 +1065,30 @@ def test_random_batches_equal_single_evaluations_bit_for_bit(gpu_engine_cls):
             want_q = [eng.site_classes(Q[b], prs[b], case.pi, bl[b]) for b in range(B)]
             assert list(got_q) == want_q, f"matrices by value, B={B}"
             assert np.isfinite(got).all() and np.isfinite(got_q).all()
+
+
+def test_batched_stencil_over_pattern_slices_adds_up(gpu_engine_cls):
+    """What a pattern-sharded fit exchanges (crabml_amd/optimize.py with world_size > 1): every rank evaluates the whole
+    stencil on its slice and the B partial sums are added in rank order.  Three slices, the last one empty (a rank left
+    without patterns on a small alignment), against the unsharded batch."""
+    from crabml_amd.dist import pattern_slices
+    c = load_case("lysozyme_m2a")
+    pi, bl = c["pi"], c["branch_lengths"]
+    B = 9
+    rng = np.random.default_rng(4)
+    kappa = 2.0 + rng.random(B)
+    omegas = np.column_stack([0.1 + 0.5 * rng.random(B), np.ones(B), 1.5 + rng.random(B)])
+    props = rng.dirichlet([5, 3, 2], size=B)
+    bls = np.tile(bl, (B, 1)) * (1 + 0.01 * rng.random((B, len(bl))))
+    with _engine(gpu_engine_cls, c["parent"], c["sequences"]) as eng:
+        whole = eng.codon_site_classes(kappa, omegas, props, pi, bls)
+        n_pat = eng.n_patterns_total
+    slices = pattern_slices(n_pat, 3, align=64)
+    assert slices[-1][0] == slices[-1][1] == n_pat and slices[0] == (0, 64)
+    total = np.zeros(B)
+    for a, b in slices:
+        with _engine(gpu_engine_cls, c["parent"], c["sequences"], pattern_begin=a, pattern_end=b) as eng:
+            part = eng.codon_site_classes(kappa, omegas, props, pi, bls)
+            assert eng.n_patterns == b - a and (a < b or np.all(part == 0.0))
+        total = total + part
+    assert np.isfinite(whole).all() and np.abs(total - whole).max() < 1e-9
