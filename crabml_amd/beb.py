@@ -202,3 +202,56 @@ def adaptive_site_posteriors(engine, model_class, mle_params, names, pi, branch_
     mean = post @ om
     se = np.sqrt(np.maximum(post @ om ** 2 - mean ** 2, 0.0))
     return post, mean, se, points, w
+
+
+# ---- the reference's front door: BEBCalculator.calculate_beb (beb.py:133-799) ------------------------------------
+from dataclasses import dataclass as _dataclass
+
+
+@_dataclass
+class BEBResult:
+    """beb.py:21-76 without the report formatting."""
+    site_numbers: np.ndarray
+    posterior_probs: np.ndarray
+    posterior_omega: np.ndarray
+    posterior_omega_se: np.ndarray
+    model_name: str
+    site_classes: list
+    class_omegas: np.ndarray
+    class_proportions: np.ndarray
+
+    def significant_sites(self, threshold: float = 0.95, class_idx: int = -1):
+        return self.site_numbers[self.posterior_probs[:, class_idx] > threshold]
+
+
+class BEBCalculator:
+    """Same constructor and ``calculate_beb()`` as the reference's (beb.py:161-188, 733-799); ``model_class`` is one of
+    crabml_amd.models' site-class models.  grid_type 'paml' (M2a only, as in the reference) integrates over PAML's 10 000
+    point grid on the device; 'adaptive' evaluates the Hessian stencil and the grid in batched calls."""
+
+    def __init__(self, mle_params, alignment, tree, model_class, param_names, fix_branch_lengths: bool = True, n_grid_points: int = 5,
+                 grid_type: str = "adaptive", device: int = 0, engine=None):
+        from .likelihood_rust import RustLikelihoodCalculator
+        self.mle_params, self.alignment, self.tree, self.model_class = dict(mle_params), alignment, tree, model_class
+        self.param_names, self.fix_branch_lengths = list(param_names), fix_branch_lengths
+        self.n_grid_points, self.grid_type = n_grid_points, grid_type
+        self.pi = models.compute_codon_frequencies_f3x4(alignment)
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)
+        self.mle_model = model_class(**self.mle_params, pi=self.pi)
+
+    def calculate_beb(self) -> BEBResult:
+        bl = self.calc._get_current_branch_lengths()
+        props, omegas = self.mle_model.get_site_classes()
+        omegas = np.asarray(omegas, dtype=np.float64)
+        if self.grid_type == "paml":
+            post, _ = m2a_site_posteriors(self.calc.engine, float(self.mle_model.kappa), self.pi, props, omegas, bl)
+        elif self.grid_type == "adaptive":
+            post, *_ = adaptive_site_posteriors(self.calc.engine, self.model_class, self.mle_params, self.param_names, self.pi, bl,
+                                                self.n_grid_points)
+        else:
+            raise ValueError(f"Unknown grid_type: {self.grid_type}. Must be 'adaptive' or 'paml'.")
+        mean = post @ omegas
+        se = np.sqrt(np.maximum(post @ omegas ** 2 - mean ** 2, 0))
+        return BEBResult(site_numbers=np.arange(1, self.alignment.n_sites + 1), posterior_probs=post, posterior_omega=mean,
+                         posterior_omega_se=se, model_name=self.model_class.__name__, site_classes=[f"ω={w:.2f}" for w in omegas],
+                         class_omegas=omegas, class_proportions=np.asarray(props, dtype=np.float64))

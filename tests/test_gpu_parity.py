@@ -1092,3 +1092,31 @@ def test_batched_stencil_over_pattern_slices_adds_up(gpu_engine_cls):
             assert eng.n_patterns == b - a and (a < b or np.all(part == 0.0))
         total = total + part
     assert np.isfinite(whole).all() and np.abs(total - whole).max() < 1e-9
+
+
+def test_beb_calculator_front_door(gpu_engine_cls):
+    """BEBCalculator(...).calculate_beb() as the reference's callers use it (analysis/positive_selection.py), on lysozyme
+    at PAML's M2a estimates: Pr(omega > 1) of the sites PAML lists, to its three printed decimals
+    (tests/data/paml_reference/lysozyme_m2a_out.txt:256-263); the adaptive grid runs end to end."""
+    from crabml_amd import beb, models
+    from crabml_amd.io import Alignment, Tree
+    aln = Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"), seqtype="codon")
+    c = load_case("lysozyme_m2a_beb")
+    # PAML's M2a branch lengths for lysozyme (data of tests/test_rust/test_paml_rust_validation.py:173-178, the tree the
+    # fixture was made with)
+    tree = Tree.from_newick("((Hsa_Human: 0.025240, Hla_gibbon: 0.041269): 0.077423, ((Cgu/Can_colobus: 0.044409, "
+                            "Pne_langur: 0.053758): 0.085025, Mmu_rhesus: 0.019175): 0.046022, (Ssc_squirrelM: 0.042962, "
+                            "Cja_marmoset: 0.024797): 0.136928);")
+    mle = dict(kappa=5.03734, omega0=0.35983, omega2=4.52341, p0=0.77376, p1=0.10399)
+    names = ["kappa", "omega0", "omega2", "p0", "p1"]
+    calc = beb.BEBCalculator(mle, aln, tree, models.M2aCodonModel, names, grid_type="paml")
+    res = calc.calculate_beb()
+    assert res.model_name == "M2aCodonModel" and res.posterior_probs.shape == (130, 3)
+    got = res.posterior_probs[np.array([15, 17, 37, 41, 50, 62, 114, 126]) - 1, 2]
+    assert np.abs(got - [0.693, 0.695, 0.744, 0.920, 0.835, 0.578, 0.689, 0.577]).max() < 5e-4
+    assert np.abs(res.posterior_probs - c["posteriors_ref"]).max() < 1e-9
+    assert list(res.significant_sites(0.9)) == [41] and np.all(res.posterior_omega_se >= 0)
+    ad = beb.BEBCalculator(mle, aln, tree, models.M2aCodonModel, names, grid_type="adaptive", n_grid_points=3).calculate_beb()
+    np.testing.assert_allclose(ad.posterior_probs.sum(axis=1), 1.0, atol=1e-12)
+    with pytest.raises(ValueError, match="Unknown grid_type"):
+        beb.BEBCalculator(mle, aln, tree, models.M2aCodonModel, names, grid_type="nope").calculate_beb()
