@@ -131,3 +131,44 @@ def m7_vs_m8(alignment, tree, **kw):
 def m8a_vs_m8(alignment, tree, **kw):
     """analysis/positive_selection.py:320-460: omega_s = 1 is on the boundary, 50:50 mixture of 0 and chi-square(1)."""
     return _compare("M8a", "M8", alignment, tree, 1, True, **kw)
+
+
+BranchModelResult = BranchSiteModelResult = SiteModelResult   # same fields (api.py:354-612 differ in report formatting only)
+
+
+def _info(opt):
+    return {"iterations": int(opt.result.nit), "calls": opt.n_calls, "parameter_vectors": opt.n_vectors, "message": str(opt.result.message)}
+
+
+def optimize_branch_model(model: str, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, **optimizer_kwargs):
+    """api.py:1214-1323: 'free-ratio' / 'model1' or 'multi-ratio' / 'model2'; an M0 fit supplies the starting kappa and omega."""
+    aln, tree_obj = _load_alignment(alignment), _load_tree(tree)
+    names = {"free-ratio": (True, "Free-ratio"), "model1": (True, "Free-ratio"), "multi-ratio": (False, "Multi-ratio"), "model2": (False, "Multi-ratio")}
+    if model.lower() not in names:
+        raise ValueError(f"Unknown branch model: '{model}'. Valid models are: 'free-ratio', 'multi-ratio'")
+    free_ratio, model_name = names[model.lower()]
+    init = {k: optimizer_kwargs.pop(k) for k in ("device", "engine", "batched_gradient") if k in optimizer_kwargs}
+    kappa0, omega0, _ = _opt.M0Optimizer(aln, tree_obj, use_f3x4=use_f3x4, **init).optimize()
+    opt = _opt.BranchModelOptimizer(aln, tree_obj, use_f3x4=use_f3x4, free_ratio=free_ratio, optimize_branch_lengths=optimize_branch_lengths, **init)
+    optimizer_kwargs.setdefault("init_kappa", kappa0)
+    optimizer_kwargs.setdefault("init_omega", omega0)
+    kappa, omega_dict, lnl = opt.optimize(**optimizer_kwargs)
+    n_params = 1 + len(omega_dict) + (opt.n_branches if optimize_branch_lengths else 1)
+    return BranchModelResult(model_name=model_name, lnL=lnl, kappa=kappa, params={"omega_dict": omega_dict}, tree=tree_obj, alignment=aln,
+                             n_params=n_params, convergence_info=_info(opt))
+
+
+def optimize_branch_site_model(model: str, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True,
+                               fix_omega: bool = False, **optimizer_kwargs):
+    """api.py:1326-1434: 'model-a' / 'branch-site-a' / 'modela'; ``fix_omega`` fits the null (omega2 = 1)."""
+    aln, tree_obj = _load_alignment(alignment), _load_tree(tree)
+    if model.lower() not in ("model-a", "branch-site-a", "modela"):
+        raise ValueError(f"Unknown branch-site model: '{model}'. Valid models are: 'model-a', 'branch-site-a'")
+    init = {k: optimizer_kwargs.pop(k) for k in ("device", "engine", "batched_gradient", "live_branch_lengths") if k in optimizer_kwargs}
+    opt = _opt.BranchSiteModelAOptimizer(aln, tree_obj, use_f3x4=use_f3x4, optimize_branch_lengths=optimize_branch_lengths,
+                                         fix_omega=fix_omega, **init)
+    kappa, omega0, omega2, p0, p1, lnl = opt.optimize(**optimizer_kwargs)
+    name = "Branch-Site Model A" + (" (null, ω₂=1)" if fix_omega else "")
+    return BranchSiteModelResult(model_name=name, lnL=lnl, kappa=kappa, params={"omega0": omega0, "omega2": omega2, "p0": p0, "p1": p1},
+                                 tree=tree_obj, alignment=aln, n_params=5 + (opt.n_branches if optimize_branch_lengths else 1),
+                                 convergence_info=_info(opt))

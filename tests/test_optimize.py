@@ -362,3 +362,27 @@ def test_optimize_model_and_the_tests_for_positive_selection():
     assert t8a["pvalue"] == 0.5 * chi2.sf(t8a["LRT"], 1) and t8a["null"].params["omega_s"] == 1.0 and t8a["null"].n_params == 15
     t12 = api.m1a_vs_m2a(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
     assert abs(t12["LRT"] - 2 * (-899.998568 + 902.503872)) < 0.1
+
+
+@pytest.mark.gpu
+def test_branch_and_branch_site_models_by_name():
+    """api.py:1214-1434: ``optimize_branch_model`` (M0 start, then the two-ratio fit) and ``optimize_branch_site_model``
+    with its null, on the reference's example files; names, params keys and counts as its parsers report them."""
+    from crabml_amd import api
+    two = "((Hsa_Human:0.05,Hla_gibbon:0.05) #1:0.05, ((Cgu/Can_colobus:0.05,Pne_langur:0.05):0.05, Mmu_rhesus:0.05):0.05, " \
+          "(Ssc_squirrelM:0.05,Cja_marmoset:0.05):0.05);"
+    r = api.optimize_branch_model("multi-ratio", os.path.join(DATA, "lysozymeSmall.txt"), two, maxiter=1000)
+    assert r.model_name == "Multi-ratio" and abs(r.lnL - (-903.076551)) < 0.5 and set(r.params["omega_dict"]) == {"omega0", "omega1"}
+    assert r.n_params == 1 + 2 + 11
+    with pytest.raises(ValueError, match="Unknown branch model"):
+        api.optimize_branch_model("three-ratio", os.path.join(DATA, "lysozymeSmall.txt"), two)
+    kw = dict(init_kappa=3.0, init_omega0=0.05, init_p0=0.35, init_p1=0.30, maxiter=500)
+    a = api.optimize_branch_site_model("model-a", os.path.join(DATA, "lysozymeLarge_clean.nuc"), os.path.join(DATA, "lysozymeLarge.trees"),
+                                       init_omega2=3.0, **kw)
+    n = api.optimize_branch_site_model("modela", os.path.join(DATA, "lysozymeLarge_clean.nuc"), os.path.join(DATA, "lysozymeLarge.trees"),
+                                       fix_omega=True, **kw)
+    assert a.model_name == "Branch-Site Model A" and abs(a.lnL - (-1035.533916)) < 0.1 and a.n_params == 5 + 33
+    assert n.model_name.endswith("(null, ω₂=1)") and n.params["omega2"] == 1.0 and n.lnL <= a.lnL + 1e-6
+    assert set(a.params) == {"omega0", "omega2", "p0", "p1"}
+    with pytest.raises(ValueError, match="Unknown branch-site model"):
+        api.optimize_branch_site_model("model-b", os.path.join(DATA, "lysozymeLarge_clean.nuc"), os.path.join(DATA, "lysozymeLarge.trees"))
