@@ -172,3 +172,14 @@ def optimize_branch_site_model(model: str, alignment, tree, use_f3x4: bool = Tru
     return BranchSiteModelResult(model_name=name, lnL=lnl, kappa=kappa, params={"omega0": omega0, "omega2": omega2, "p0": p0, "p1": p1},
                                  tree=tree_obj, alignment=aln, n_params=5 + (opt.n_branches if optimize_branch_lengths else 1),
                                  convergence_info=_info(opt))
+
+
+def positive_selection(alignment, tree, test: str = "both", verbose: bool = False, **kw):
+    """analysis/positive_selection.py:463-end: one of the three tests by name, or M1a-M2a and M7-M8 together."""
+    key = test.lower().replace("_", "").replace("-", "")
+    if key == "both":
+        return {"M1a_vs_M2a": m1a_vs_m2a(alignment, tree, **kw), "M7_vs_M8": m7_vs_m8(alignment, tree, **kw)}
+    tests = {"m1avsm2a": m1a_vs_m2a, "m1avm2a": m1a_vs_m2a, "m7vsm8": m7_vs_m8, "m7vm8": m7_vs_m8, "m8avsm8": m8a_vs_m8, "m8avm8": m8a_vs_m8}
+    if key not in tests:
+        raise ValueError(f"Unknown test: '{test}'. Must be 'M1a_vs_M2a', 'M7_vs_M8', 'M8a_vs_M8', or 'both'.")
+    return tests[key](alignment, tree, **kw)

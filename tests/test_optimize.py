@@ -339,6 +339,8 @@ def test_api_loaders_and_model_names():
         api._load_tree("((a,b")
     with pytest.raises(ValueError, match="Unknown model: 'M99'"):
         api.optimize_model("M99", aln, t)
+    with pytest.raises(ValueError, match="Unknown test: 'M0_vs_M3'"):
+        api.positive_selection(aln, t, test="M0_vs_M3")
 
 
 @pytest.mark.gpu
@@ -360,8 +362,10 @@ def test_optimize_model_and_the_tests_for_positive_selection():
     assert set(t78["alternative"].params) == {"p0", "p", "q", "omega_s"} and set(t78["null"].params) == {"p", "q"}
     t8a = api.m8a_vs_m8(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
     assert t8a["pvalue"] == 0.5 * chi2.sf(t8a["LRT"], 1) and t8a["null"].params["omega_s"] == 1.0 and t8a["null"].n_params == 15
-    t12 = api.m1a_vs_m2a(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
-    assert abs(t12["LRT"] - 2 * (-899.998568 + 902.503872)) < 0.1
+    both = api.positive_selection(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START)
+    assert set(both) == {"M1a_vs_M2a", "M7_vs_M8"} and abs(both["M1a_vs_M2a"]["LRT"] - 2 * (-899.998568 + 902.503872)) < 0.1
+    assert both["M7_vs_M8"]["LRT"] == t78["LRT"]                                # deterministic from the same start
+    assert api.positive_selection(os.path.join(DATA, "lysozymeSmall.txt"), LYSOZYME_START, test="M8a-vs-M8")["df"] == 1
 
 
 @pytest.mark.gpu
