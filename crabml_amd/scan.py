@@ -49,9 +49,15 @@ def lrt_gene(engine, alignment, tree, null: str = "M7", ncatG: int = 10, maxiter
 
 def scan(genes, null: str = "M7", rank: int = 0, world_size: int = 1, workers: int = 8, group=None, make_engine=None, **kw):
     """``genes``: a list of (alignment, tree), the same list on every rank.  Returns the per-gene results in order on
-    every rank (``torch.distributed.all_gather_object`` of this rank's rows when world_size > 1)."""
+    every rank; a gene whose fit raises yields ``{"null": ..., "error": message}`` instead of ending the scan (``torch.distributed.all_gather_object`` of this rank's rows when world_size > 1)."""
     mine = list(gene_shard(len(genes), rank, world_size))
-    rows = map_genes(lambda eng, i: lrt_gene(eng, genes[i][0], genes[i][1], null=null, **kw), mine, workers=workers, make_engine=make_engine)
+    def one(eng, i):
+        try:
+            return lrt_gene(eng, genes[i][0], genes[i][1], null=null, **kw)
+        except Exception as e:   # noqa: BLE001 -- one unusable gene (names that do not match, no codons) must not end a 10 000-gene scan
+            return {"null": null, "error": f"{type(e).__name__}: {e}"}
+
+    rows = map_genes(one, mine, workers=workers, make_engine=make_engine)
     out = [None] * len(genes)
     if world_size > 1:
         import torch.distributed as dist

@@ -253,6 +253,13 @@ def test_two_rank_gloo_gene_scan_equals_the_single_rank_scan():
         alone = [(r["lnL_null"], r["lnL_M8"], r["LRT"], r["pvalue"])
                  for r in scan.scan(_scan_genes(), null="M7", workers=1, make_engine=_OracleEngine, ncatG=2, maxiter=2, init_with_m0=False)]
     assert res[0] == res[1] == alone and len(alone) == 4
+    from crabml_amd.io import Alignment
+    bad = _scan_genes()[:2]
+    bad[1] = (Alignment.from_codes(["x%d" % i for i in range(7)], np.asarray(bad[1][0].sequences)), bad[1][1])   # names not in the tree
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rows = scan.scan(bad, workers=1, make_engine=_OracleEngine, ncatG=2, maxiter=1, init_with_m0=False)
+    assert "LRT" in rows[0] and rows[1]["error"].startswith("ValueError: Alignment and tree have different species")
     for l7, l8, stat, p in alone:
         assert np.isfinite(l7) and np.isfinite(l8) and stat >= 0 and 0 <= p <= 1
         assert stat == max(0.0, 2 * (l8 - l7))
