@@ -309,12 +309,15 @@ class BranchSiteModelAOptimizer:
     parameters through (what the docstring of the reference promises); every row is then distinct."""
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, fix_omega: bool = False,
-                 device: int = 0, batched_gradient: bool = True, engine=None, live_branch_lengths: bool = False):
+                 device: int = 0, batched_gradient: bool = True, engine=None, live_branch_lengths: bool = False,
+                 rank: int = 0, world_size: int = 1, group=None):
         self.alignment, self.tree = alignment, tree
+        self.rank, self.world_size, self.group = rank, world_size, group
         self.use_f3x4, self.optimize_branch_lengths, self.fix_omega = use_f3x4, optimize_branch_lengths, fix_omega
         self.batched_gradient, self.live_branch_lengths = batched_gradient, live_branch_lengths
         self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
-        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine,      # world_size > 1: as the site-class fits
+                                             pattern_slice=_SiteClassOptimizer._pattern_slice(alignment, rank, world_size))
         self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]
         self.n_branches = len(self.branch_nodes)
         self._branch_rows = np.array([self.calc.node_id_map[v] for v in self.branch_nodes])
@@ -355,6 +358,9 @@ class BranchSiteModelAOptimizer:
         q = np.array([self._unpack(p) for p in rows])
         lnl = self.calc.engine.codon_branch_site(q[:, 0], q[:, 1], q[:, 2], q[:, 3], q[:, 4], self.pi,
                                                  np.ascontiguousarray(self._branch_lengths(rows)), self.branch_labels_u8)
+        if self.world_size > 1:
+            from .dist import ordered_sum_vector
+            lnl = ordered_sum_vector(lnl, self.group)
         self.n_calls += 1
         self.n_vectors += len(rows)
         self.n_rows += len(params)
@@ -402,13 +408,15 @@ class BranchModelOptimizer:
     are written back to the tree in the boundary's order, i.e. onto the nodes they were evaluated on."""
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, free_ratio: bool = False,
-                 device: int = 0, batched_gradient: bool = True, engine=None):
+                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None):
         if not optimize_branch_lengths:
             raise NotImplementedError("Global branch scaling not yet implemented")     # as the reference
+        self.rank, self.world_size, self.group = rank, world_size, group
         self.alignment, self.tree, self.use_f3x4, self.free_ratio = alignment, tree, use_f3x4, free_ratio
         self.optimize_branch_lengths, self.batched_gradient = optimize_branch_lengths, batched_gradient
         self.pi = models.compute_codon_frequencies_f3x4(alignment) if use_f3x4 else np.ones(61) / 61
-        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine)
+        self.calc = RustLikelihoodCalculator(alignment, tree, device=device, engine=engine,
+                                             pattern_slice=_SiteClassOptimizer._pattern_slice(alignment, rank, world_size))
         order = self.calc.postorder_nodes                                              # leaves first, then internals; root last
         labels = np.array([int(tree.label[v]) if tree.parent[v] >= 0 else 0 for v in order])
         self.branch_nodes = [v for v in tree.postorder() if tree.parent[v] >= 0]
@@ -428,6 +436,9 @@ class BranchModelOptimizer:
         bl = np.tile(self._template, (len(params), 1))
         bl[:, :-1] = np.exp(params[:, 1 + n_w:])
         lnl = np.asarray(self.calc.engine.codon_branch(kappa, np.ascontiguousarray(omegas[:, self.model.omega_labels]), self.pi, bl))
+        if self.world_size > 1:
+            from .dist import ordered_sum_vector
+            lnl = ordered_sum_vector(lnl, self.group)
         self.n_calls += 1
         self.n_vectors += len(params)
         self.history.append({"kappa": float(kappa[0]), "omega": {f"omega{i}": float(omegas[0, i]) for i in range(n_w)},
