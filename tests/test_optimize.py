@@ -390,3 +390,27 @@ def test_branch_and_branch_site_models_by_name():
     assert set(a.params) == {"omega0", "omega2", "p0", "p1"}
     with pytest.raises(ValueError, match="Unknown branch-site model"):
         api.optimize_branch_site_model("model-b", os.path.join(DATA, "lysozymeLarge_clean.nuc"), os.path.join(DATA, "lysozymeLarge.trees"))
+
+
+@pytest.mark.gpu
+def test_gene_scan_on_the_device():
+    """crabml_amd/scan.py with real engines: three small genes over two engines sharing the card give, gene for gene,
+    what one engine gives alone (fits are deterministic; engines are re-targeted between genes)."""
+    import warnings
+    from crabml_amd import scan
+    from crabml_amd.engine import Engine
+    from crabml_amd.io import Alignment, Tree
+    aln = Alignment.from_phylip(os.path.join(DATA, "lysozymeSmall.txt"), seqtype="codon")
+    codes = np.asarray(aln.sequences)
+    genes = [(Alignment.from_codes(aln.names, codes[:, lo:lo + 60]), Tree.from_newick(LYSOZYME_START)) for lo in (0, 35, 70)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                               # a negative statistic on 60 codons only warns
+        rows = scan.scan(genes, null="M7", workers=2)
+        with Engine(0) as eng:
+            alone = [scan.lrt_gene(eng, a, t, null="M7") for a, t in genes]
+        mixture = scan.scan(genes[:1], null="M8a", workers=1)
+    for r, a in zip(rows, alone):
+        assert "error" not in r and (r["lnL_null"], r["lnL_M8"], r["LRT"], r["pvalue"]) == (a["lnL_null"], a["lnL_M8"], a["LRT"], a["pvalue"])
+        assert r["LRT"] >= 0 and 0 <= r["pvalue"] <= 1 and r["fits"]["M8"]["vectors"] > r["fits"]["M8"]["calls"]
+    assert mixture[0]["null"] == "M8a" and 0 <= mixture[0]["pvalue"] <= 1
+    assert genes[0][1].branch_length.max() == 0.05                   # the caller's trees are left alone
