@@ -1120,3 +1120,9 @@ def test_beb_calculator_front_door(gpu_engine_cls):
     np.testing.assert_allclose(ad.posterior_probs.sum(axis=1), 1.0, atol=1e-12)
     with pytest.raises(ValueError, match="Unknown grid_type"):
         beb.BEBCalculator(mle, aln, tree, models.M2aCodonModel, names, grid_type="nope").calculate_beb()
+    # M8 through the adaptive grid (the reference's default for it): 11 classes, beta shape parameters in the Hessian
+    mle8 = dict(kappa=5.029752, p0=0.868486, p_beta=9.517504, q_beta=13.543157, omega_s=4.370617, ncatG=10)
+    r8 = beb.BEBCalculator(mle8, aln, tree, models.M8CodonModel, ["kappa", "p0", "p_beta", "q_beta", "omega_s"], n_grid_points=3).calculate_beb()
+    assert r8.posterior_probs.shape == (130, 11) and r8.class_omegas[-1] == 4.370617 and len(r8.site_classes) == 11
+    np.testing.assert_allclose(r8.posterior_probs.sum(axis=1), 1.0, atol=1e-12)
+    assert r8.posterior_probs[40, -1] > 0.8 and r8.posterior_probs[40, -1] == r8.posterior_probs[:, -1].max()      # site 41 again
