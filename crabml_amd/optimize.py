@@ -125,7 +125,6 @@ class _SiteClassOptimizer:
                                                   np.array([c[1] for c in cls], dtype=np.float64)[row_model],
                                                   np.array([c[0] for c in cls], dtype=np.float64)[row_model], self.pi,
                                                   self._branch_lengths(params))
-        classes = [distinct[row_model[0]]]
         if self.world_size > 1:
             from .dist import ordered_sum_vector
             lnl = ordered_sum_vector(lnl, self.group)
@@ -133,7 +132,7 @@ class _SiteClassOptimizer:
         self.n_vectors += len(params)
         if self.optimize_branch_lengths:                                   # the reference leaves the last values in the tree
             self.tree.branch_length[np.array(self.branch_nodes)] = np.exp(params[0, self.n_model:self.n_model + self.n_branches])
-        self.history.append(self.record(classes[0], float(lnl[0])))
+        self.history.append(self.record(distinct[row_model[0]], float(lnl[0])))
         return -lnl
 
     def compute_log_likelihood(self, params):
