@@ -43,10 +43,11 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(case, sample_sites=5000, reps=2):
+def cpu_baseline(case, sample_sites=10000, reps=5):
     """The oracle (CPU restatement of the Rust path, reference mode) on a bounded sample of the same workload,
     one thread per site class like the reference's Rayon loop (likelihood.rs:267)."""
     from oracle import oracle as orc
+    sample_sites = min(sample_sites, case.n_sites)      # about 10 s of CPU work on the box: the whole alignment, five times each way
     codes = np.ascontiguousarray(case.codes[:, :sample_sites])
     K = len(case.proportions)
     threads = min(K, os.cpu_count() or 1, 16)
