@@ -110,6 +110,11 @@ double now_ms()
 
 uint64_t hash_words(const void *p, size_t bytes, uint64_t seed);
 
+namespace crab {
+// for entry points that live in other source files (crab_noalloc.hip): the message crab_last_error(NULL) returns
+void set_global_error(const std::string &msg) { g_last_error = msg; }
+}  // namespace crab
+
 // Device-resident pool of spectral decompositions.  Finite-difference gradients perturb one parameter at a time, and a
 // branch-length perturbation changes no rate matrix at all, so most of the K (site classes) or n_nodes (free-ratio)
 // decompositions of a call repeat those of the call before (lib.rs:163-169,387-393 redo all of them).  An entry is

@@ -199,6 +199,16 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out);
 /* matrix_exponential (lib.rs:61-79 -> matrix.rs:31-102): P = exp(Q t), computed on the device
  * with the same batched kernel the evaluations use.  P_out: [n][n]. */
 int crab_matrix_exponential(int device, int n, const double *Q, const double *pi, double t, double *P_out);
+/* crab_matrix_exponential for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose expm allocates a fresh ndarray
+ * per call, matrix.rs:88-102).  Same arguments and results as crab_matrix_exponential (bit-identical: same host
+ * decomposition, same kernel); the eigensystem, time and output images that crab_matrix_exponential stages in
+ * device buffers allocated per call live in a file-scope device array instead -- 131 616 bytes per GPU, held from the
+ * first call on that GPU until the process ends.  Calls no hipMalloc / hipFree / hipHostMalloc.  Limit: n <= 63 (one
+ * 64-state eigensystem and one transition matrix); larger n is CRAB_ERR_ARG.  Every call on a GPU shares that GPU's
+ * array: calls from several threads of one process are serialised inside the library; the array keeps the last
+ * call's contents, each call overwrites everything its kernel reads. */
+int crab_matrix_exponential_noalloc(int device, int n, const double *Q, const double *pi, double t, double *P_out);
 /* build_codon_q_matrix_py (lib.rs:445-463 -> qmatrix.rs:22-80).  Host only. */
 int crab_build_codon_q_matrix(double kappa, double omega, const double *pi, int has_normalization_factor,
                               double normalization_factor, double *Q_out);
