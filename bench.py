@@ -34,13 +34,16 @@ N_TAXA, N_SITES, SEED = 100, 10000, 2
 
 def pmc_traffic():
     """HBM-side bytes per launch of the pruning kernel, from the committed rocprofv3 --pmc passes over this same
-    workload (profiles/r1_pmc_c2.json: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).  A counter
+    workload (profiles/rN_pmc_c2.json, newest round: FETCH_SIZE doubled per the gfx950 correction, plus WRITE_SIZE).  A counter
     run cannot share a process with the timed run, so this is a recorded figure, not a live one; None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_c2.json")) as fh:
-            return float(json.load(fh)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c2.json")), reverse=True):   # newest round first
+        try:
+            with open(path) as fh:
+                return float(json.load(fh)["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(case, sample_sites=10000, reps=5):
@@ -81,6 +84,85 @@ def cpu_baseline(case, sample_sites=10000, reps=5):
     out["all_cores"] = {"value": updates / best_all, "cores": cores, "host_cpus": os.cpu_count(),
                         "lnl_evals_per_s": 1.0 / (best_all * case.n_sites / sample_sites),
                         "note": "same sample split into one block of sites per core, single-threaded oracle call per block"}
+    out["blas"] = cpu_baseline_blas(case, codes, threads, reps=3)
+    return out
+
+
+def cpu_baseline_blas(case, codes, threads, reps=3):
+    """The same reference-mode algorithm with the per-edge product done by the BLAS numpy ships (OpenBLAS dgemm, which
+    is what crabML's ndarray `dot` calls, likelihood.rs:189): one thread per class, BLAS pinned to one thread per call.
+    Of the two CPU legs this is the one closer to crabML's Rust + OpenBLAS path; the hand-loop port stays beside it."""
+    from oracle import blas_baseline as bb
+    sample_sites = codes.shape[1]
+    K = len(case.proportions)
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        bb.site_class_log_likelihood(case.Q, case.proportions, case.pi, case.parent, case.branch_lengths, codes, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+    updates = sample_sites * (case.n_nodes - 1) * K
+    return {"value": updates / best, "unit": "CL updates/s", "cores": threads, "kind": "port",
+            "lnl_evals_per_s": 1.0 / (best * case.n_sites / sample_sites), "blas": bb.blas_vendor(),
+            "gflops": updates * FLOP_PER_UPDATE / best / 1e9,
+            "note": f"numpy restatement of likelihood.rs:176-195 with dgemm per child edge (M = {sample_sites}, N = K = 61), "
+                    f"{sample_sites} codons, best of {reps}"}
+
+
+def target_workload(device, with_cpu=True, evals=8, cpu_sample=1000):
+    """BASELINE.json north_star's target: M8 on a 500-taxon x 50 000-codon alignment (here: the whole alignment on ONE
+    MI355X; an 8-GPU run shards its patterns).  Reported beside the headline line, never as `value`."""
+    from crabml_amd import models, synth
+    from crabml_amd.engine import Engine
+    n_taxa, n_sites = 500, 50000
+    case = synth.make_case("M8", n_taxa, n_sites, seed=6)
+    K = len(case.proportions)
+    Qs = []
+    for i in range(evals + 2):     # a new kappa per evaluation: the eigensystem pool must not be what is timed
+        m = models.M8CodonModel(kappa=case.kappa * (1.0 + 1e-7 * i), p0=0.9, p_beta=0.7, q_beta=1.5, omega_s=2.5, ncatG=10, pi=case.pi)
+        Qs.append(np.ascontiguousarray(np.stack(m.get_Q_matrices())))
+    with Engine(device) as eng:
+        eng.set_tree(case.parent, case.leaf_node_ids)
+        eng.set_alignment(case.codes, n_states=61)
+        for Q in Qs[:2]:
+            lnL = eng.site_classes(Q, case.proportions, case.pi, case.branch_lengths)
+        prune = []
+        t0 = time.perf_counter()
+        for Q in Qs[2:]:
+            lnL = eng.site_classes(Q, case.proportions, case.pi, case.branch_lengths)
+            prune.append(eng.last_timing()[1])
+        dt = (time.perf_counter() - t0) / evals
+        dense, gather = eng.last_work()
+        n_pat = eng.n_patterns
+    kernel_ms = float(np.mean(prune))
+    tflops = dense * FLOP_PER_UPDATE / (kernel_ms * 1e-3) / 1e12
+    updates_per_eval = n_sites * (case.n_nodes - 1) * K
+    out = {"workload": "north_star target: M8 (11 classes), 500 taxa x 50000 codons, whole alignment on one MI355X, tree length "
+                       "%.2f subst/codon" % case.tree_length,
+           "lnl_evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt, "cl_updates_per_s": updates_per_eval / dt, "patterns": n_pat,
+           "prune_kernel_ms": kernel_ms, "prune_tflops": tflops, "roofline_frac": tflops / FP64_MFMA_PEAK_TFLOPS, "lnL": lnL,
+           "dense_updates_per_launch": dense}
+    if with_cpu:
+        from oracle import oracle as orc
+        from oracle import blas_baseline as bb
+        cols = np.linspace(0, n_sites - 1, cpu_sample).astype(int)
+        codes = np.ascontiguousarray(case.codes[:, cols])
+        threads = min(K, os.cpu_count() or 1, 16)
+        best_port = best_blas = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.compute_site_class_log_likelihood(list(case.Q), case.proportions, case.pi, case.tree_structure, case.branch_lengths,
+                                                  None, codes, case.leaf_node_ids, threads=threads)
+            best_port = min(best_port, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            bb.site_class_log_likelihood(case.Q, case.proportions, case.pi, case.parent, case.branch_lengths, codes, threads=threads)
+            best_blas = min(best_blas, time.perf_counter() - t0)
+        scale = n_sites / cpu_sample
+        out["cpu_baseline"] = {
+            "cores": threads, "kind": "port", "blas": bb.blas_vendor(),
+            "lnl_evals_per_s_port": 1.0 / (best_port * scale), "lnl_evals_per_s_blas": 1.0 / (best_blas * scale),
+            "sample": f"{cpu_sample} of {n_sites} codons (every {n_sites // cpu_sample}th column), all {K} classes, all "
+                      f"{case.n_nodes - 1} branches dense, best of 3; evals/s scaled linearly in the number of codons"}
+        out["gpu_over_cpu_one_gpu"] = {"vs_port": (1.0 / dt) * best_port * scale, "vs_blas": (1.0 / dt) * best_blas * scale}
     return out
 
 
@@ -90,6 +172,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-target", action="store_true", help="skip the north_star target workload block (M8, 500 taxa x 50 000 codons)")
     ap.add_argument("--fd-batch", type=int, default=0,
                     help="also time crab_eval_site_classes_batch with this many perturbed vectors per call (auxiliary line; "
                          "off by default so that a rocprofv3 --stats run of the default command averages single evaluations only)")
@@ -113,21 +196,30 @@ def main():
     if os.environ.get("CRAB_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    data_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # The ranks must agree on the backend: a rank that fell back to gloo on its own while the others sit in an
+            # RCCL collective would hang the job.  The default group is gloo (control plane: barriers, the agreement
+            # below); the data path is an RCCL group created beside it and probed once, and the probe's outcome is
+            # agreed over gloo (MIN over ranks): either every rank uses RCCL or the run stops.  There is no silent
+            # downgrade: a line reporting collective "rccl" did exchange over RCCL.
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ok = 1
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                data_group = dist.new_group(backend="nccl")
                 probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)          # RCCL communicators are created lazily: fail here, not in the timed loop
+                dist.all_reduce(probe, group=data_group)   # RCCL communicators are created lazily: fail here, not in the timed loop
                 torch.cuda.synchronize()
-            except Exception as exc:            # one double per rank and step: gloo over loopback carries it as well
-                print(f"[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); falling back to gloo", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            except Exception as exc:
+                print(f"[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
+                ok, data_group = 0, None
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise SystemExit("bench.py: RCCL could not be initialised on every rank; not falling back "
+                                 "(set CRAB_BENCH_BACKEND=gloo to rehearse the control flow without RCCL)")
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -151,7 +243,7 @@ def main():
 
     def step():
         partial = eng.site_classes(next(it), case.proportions, case.pi, case.branch_lengths)
-        return ordered_sum(partial)
+        return ordered_sum(partial, group=data_group)
 
     def fence():
         if world > 1:
@@ -172,8 +264,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # default (gloo) group
         elapsed = float(t.item())
 
     dense, gather = eng.last_work()
@@ -228,8 +320,11 @@ def main():
                                  "note": "auxiliary, not the headline: perturbed branch-length vectors, one call per batch"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case)
-        print(json.dumps(out), flush=True)
     eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_target:
+            out["target_workload"] = target_workload(local_rank, with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,11 +31,21 @@ __all__ = ["matrix_exponential", "compute_log_likelihood", "compute_site_class_l
 
 
 def _device() -> int:
+    """CRAB_DEVICES=0,1,...: every listed GPU behind one handle (-1 tells the C library to read the list);
+    else CRAB_DEVICE or LOCAL_RANK; else device 0."""
+    if os.environ.get("CRAB_DEVICES", "").strip():
+        return -1
     for var in ("CRAB_DEVICE", "LOCAL_RANK"):
         v = os.environ.get(var)
         if v is not None and v.strip().lstrip("-").isdigit():
             return int(v)
     return 0
+
+
+def _single_device() -> int:
+    """For the calls that use one GPU whatever the list says (matrix_exponential): the first of CRAB_DEVICES."""
+    first = os.environ.get("CRAB_DEVICES", "").split(",")[0].strip()
+    return int(first) if first.lstrip("-").isdigit() else max(_device(), 0)
 
 
 def _square(q, what="q"):
@@ -70,6 +80,14 @@ def _seq(sequences):
     return s
 
 
+def _leaf_ids(leaf_node_ids, n_rows):
+    """One node id per alignment row: the C library reads exactly n_rows of them."""
+    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32).reshape(-1)
+    if len(leaf) != n_rows:
+        raise ValueError(f"leaf_node_ids has {len(leaf)} entries but sequences has {n_rows} rows")
+    return leaf
+
+
 def _branch_lengths(branch_lengths, n_nodes):
     bl = np.ascontiguousarray(branch_lengths, dtype=np.float64).reshape(-1)
     if len(bl) < n_nodes:
@@ -83,7 +101,7 @@ def matrix_exponential(q, pi, t):
     n = Q.shape[0]
     p = _pi_for(pi, n)
     out = np.empty((n, n))
-    L.check(L.load().crab_matrix_exponential(_device(), n, Q.ctypes.data_as(L.dp), p.ctypes.data_as(L.dp), float(t),
+    L.check(L.load().crab_matrix_exponential(_single_device(), n, Q.ctypes.data_as(L.dp), p.ctypes.data_as(L.dp), float(t),
                                              out.ctypes.data_as(L.dp)))
     return out
 
@@ -96,7 +114,7 @@ def compute_log_likelihood(q, pi, tree_structure, branch_lengths, leaf_names, se
     ids, par = tree_arrays(tree_structure)
     bl = _branch_lengths(branch_lengths, len(ids))
     seq = _seq(sequences)
-    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32)
+    leaf = _leaf_ids(leaf_node_ids, seq.shape[0])
     out = C.c_double()
     L.check(L.load().crab_compute_log_likelihood(_device(), n, Q.ctypes.data_as(L.dp), p.ctypes.data_as(L.dp), len(ids),
                                                  ids.ctypes.data_as(L.ip), par.ctypes.data_as(L.ip), bl.ctypes.data_as(L.dp),
@@ -116,7 +134,7 @@ def compute_site_class_log_likelihood(q_matrices, proportions, pi, tree_structur
     ids, par = tree_arrays(tree_structure)
     bl = _branch_lengths(branch_lengths, len(ids))
     seq = _seq(sequences)
-    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32)
+    leaf = _leaf_ids(leaf_node_ids, seq.shape[0])
     out = C.c_double()
     L.check(L.load().crab_compute_site_class_log_likelihood(
         _device(), Q.shape[0], n, Q.ctypes.data_as(L.dp), pr.ctypes.data_as(L.dp), p.ctypes.data_as(L.dp), len(ids),
@@ -133,7 +151,7 @@ def compute_site_log_likelihoods_by_class(q_matrices, pi, tree_structure, branch
     ids, par = tree_arrays(tree_structure)
     bl = _branch_lengths(branch_lengths, len(ids))
     seq = _seq(sequences)
-    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32)
+    leaf = _leaf_ids(leaf_node_ids, seq.shape[0])
     out = np.empty((seq.shape[1], Q.shape[0]))
     L.check(L.load().crab_compute_site_log_likelihoods_by_class(
         _device(), Q.shape[0], n, Q.ctypes.data_as(L.dp), p.ctypes.data_as(L.dp), len(ids), ids.ctypes.data_as(L.ip),
@@ -158,7 +176,7 @@ def compute_branch_site_log_likelihood(q_omega0, q_omega1, q_omega2, qfactor_bac
     bl = _branch_lengths(branch_lengths, len(ids))
     lab = np.ascontiguousarray(branch_labels, dtype=np.uint8)
     seq = _seq(sequences)
-    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32)
+    leaf = _leaf_ids(leaf_node_ids, seq.shape[0])
     out = C.c_double()
     L.check(L.load().crab_compute_branch_site_log_likelihood(
         _device(), n, Q0.ctypes.data_as(L.dp), Q1.ctypes.data_as(L.dp), Q2.ctypes.data_as(L.dp), float(qfactor_back),
@@ -175,7 +193,7 @@ def compute_log_likelihood_branch(sequences, parent_indices, leaf_node_ids, Q_ma
     par = np.ascontiguousarray([-1 if int(x) < 0 else int(x) for x in parent_indices], dtype=np.int32)
     bl = np.ascontiguousarray(branch_lengths, dtype=np.float64).reshape(-1)
     seq = _seq(sequences)
-    leaf = np.ascontiguousarray(leaf_node_ids, dtype=np.int32)
+    leaf = _leaf_ids(leaf_node_ids, seq.shape[0])
     out = C.c_double()
     L.check(L.load().crab_compute_log_likelihood_branch(
         _device(), n, seq.ctypes.data_as(L.ip), seq.shape[0], seq.shape[1], par.ctypes.data_as(L.ip), len(par),

@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <atomic>
 #include <thread>
 #include <cmath>
@@ -232,6 +234,163 @@ struct EigPool {
     }
 };
 
+// Host-side cache of packed decompositions shared by the engines of one multi-device handle (crab_create_multi): every
+// device needs every eigensystem, so the first shard to ask for one computes it and the others copy it (an 8-GPU handle
+// would otherwise decompose each rate matrix eight times on the same host cores).  Keyed like EigPool.
+struct SharedEigCache {
+    struct Item {
+        bool by_params = false, ready = false, failed = false;
+        double kappa = 0, omega = 0;
+        std::vector<double> Q, pi, packed;
+        uint64_t stamp = 0;
+    };
+    static constexpr size_t MAX_ITEMS = 4096;   // x 66 KB = 270 MB of host memory
+    std::mutex m;
+    std::condition_variable cv;
+    std::unordered_multimap<uint64_t, std::shared_ptr<Item>> map;
+    uint64_t clock = 0;
+
+    // Copies the decomposition for this key into out (EIG_STRIDE doubles), running compute(out) if nobody has yet.
+    bool get(uint64_t h, bool by_params, double kappa, double omega, const double *Q, const double *pi, int n, double *out,
+             const std::function<bool(double *)> &compute)
+    {
+        std::shared_ptr<Item> it;
+        bool mine = false;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            auto r = map.equal_range(h);
+            for (auto i = r.first; i != r.second; ++i) {
+                Item &c = *i->second;
+                if (c.by_params != by_params || std::memcmp(c.pi.data(), pi, sizeof(double) * n) != 0) continue;
+                if (by_params ? (std::memcmp(&c.kappa, &kappa, 8) == 0 && std::memcmp(&c.omega, &omega, 8) == 0)
+                              : std::memcmp(c.Q.data(), Q, sizeof(double) * n * n) == 0) {
+                    it = i->second;
+                    break;
+                }
+            }
+            if (!it) {
+                it = std::make_shared<Item>();
+                it->by_params = by_params;
+                it->kappa = kappa;
+                it->omega = omega;
+                it->pi.assign(pi, pi + n);
+                if (!by_params) it->Q.assign(Q, Q + (size_t)n * n);
+                map.emplace(h, it);
+                mine = true;
+                if (map.size() > MAX_ITEMS) evict_locked();
+            }
+            it->stamp = ++clock;
+            if (!mine) {
+                cv.wait(lk, [&] { return it->ready || it->failed; });
+                if (it->failed) return false;
+                std::memcpy(out, it->packed.data(), sizeof(double) * crab::EIG_STRIDE);
+                return true;
+            }
+        }
+        const bool ok = compute(out);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (ok) {
+                it->packed.assign(out, out + crab::EIG_STRIDE);
+                it->ready = true;
+            } else {
+                it->failed = true;
+                auto r = map.equal_range(h);
+                for (auto i = r.first; i != r.second; ++i)
+                    if (i->second == it) {
+                        map.erase(i);
+                        break;
+                    }
+            }
+        }
+        cv.notify_all();
+        return ok;
+    }
+    void evict_locked()   // drop the least recently used quarter (finished entries only)
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> old;   // (stamp, hash)
+        for (auto &kv : map)
+            if (kv.second->ready) old.emplace_back(kv.second->stamp, kv.first);
+        std::sort(old.begin(), old.end());
+        const size_t drop = old.size() / 4;
+        for (size_t i = 0; i < drop; ++i) {
+            auto r = map.equal_range(old[i].second);
+            for (auto it = r.first; it != r.second; ++it)
+                if (it->second->ready && it->second->stamp == old[i].first) {
+                    map.erase(it);
+                    break;
+                }
+        }
+    }
+};
+
+// One persistent host thread per shard of a multi-device handle (shard 0 runs on the caller's thread).
+class ShardWorkers {
+    struct Slot {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has_job = false, done = true, stop = false;
+    };
+    std::vector<std::unique_ptr<Slot>> slots_;
+
+  public:
+    void start(int n)
+    {
+        for (int i = 0; i < n; ++i) {
+            slots_.emplace_back(new Slot());
+            Slot *s = slots_.back().get();
+            s->th = std::thread([s] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(s->m);
+                        s->cv.wait(lk, [&] { return s->has_job || s->stop; });
+                        if (s->stop) return;
+                        job.swap(s->job);
+                        s->has_job = false;
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lk(s->m);
+                        s->done = true;
+                    }
+                    s->cv.notify_all();
+                }
+            });
+        }
+    }
+    void post(int i, std::function<void()> job)
+    {
+        Slot *s = slots_[i].get();
+        {
+            std::lock_guard<std::mutex> lk(s->m);
+            s->job = std::move(job);
+            s->has_job = true;
+            s->done = false;
+        }
+        s->cv.notify_all();
+    }
+    void wait(int i)
+    {
+        Slot *s = slots_[i].get();
+        std::unique_lock<std::mutex> lk(s->m);
+        s->cv.wait(lk, [&] { return s->done; });
+    }
+    ~ShardWorkers()
+    {
+        for (auto &sp : slots_) {
+            {
+                std::lock_guard<std::mutex> lk(sp->m);
+                sp->stop = true;
+            }
+            sp->cv.notify_all();
+            if (sp->th.joinable()) sp->th.join();
+        }
+    }
+};
+
 // The tree compiled for the device: topology tables plus the flat post-order op list.
 struct TreeProgram {
     int n_nodes = 0, root = -1, n_leaf_rows = 0;
@@ -271,6 +430,13 @@ struct crab_engine : TreeProgram {
     EigPool eig_pool;
     int64_t eig_hits = 0, eig_misses = 0;
 
+    // ---- multi-device handle (crab_create_multi): this engine owns no device itself, its shards do ----
+    std::vector<crab_engine *> shards;
+    std::unique_ptr<ShardWorkers> workers;
+    std::unique_ptr<SharedEigCache> shared_eig_owner;
+    SharedEigCache *shared_eig = nullptr;   // set on the shards of a multi-device handle
+    bool is_multi() const { return !shards.empty(); }
+
     // ---- last-eval facts ----
     std::vector<int32_t> last_pidx;  // [K][n_nodes] of the last evaluation
     int last_K = 0, last_M = 0;
@@ -279,6 +445,9 @@ struct crab_engine : TreeProgram {
 
     ~crab_engine()
     {
+        workers.reset();
+        for (crab_engine *sh : shards) delete sh;
+        if (is_multi()) return;   // owns no device state of its own
         (void)hipSetDevice(device);
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
@@ -336,8 +505,9 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
         const int v = node_ids ? node_ids[k] : k;
         if (v < 0 || v >= n_nodes) fail(CRAB_ERR_ARG, "tree_structure: node id " + std::to_string(v) + " out of range");
         if (parents[k] >= n_nodes) fail(CRAB_ERR_ARG, "tree_structure: parent id " + std::to_string(parents[k]) + " out of range");
+        if (seen[v]) fail(CRAB_ERR_ARG, "tree_structure: node id " + std::to_string(v) + " appears more than once");
         e->parent[v] = parents[k] < 0 ? -1 : parents[k];
-        seen[v] = 1;
+        seen[v] = 1;   // n_nodes distinct ids in [0, n_nodes): every node is listed exactly once
     }
     // children in order of appearance (likelihood.rs:49-54)
     e->child_start.assign(n_nodes + 1, 0);
@@ -655,20 +825,37 @@ void compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int 
     }
 }
 
-void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
-                    int64_t pat_begin, int64_t pat_end)
+// The alignment after pattern compression, before slicing: computed once per crab_set_alignment, shared by the shards
+// of a multi-device handle.
+struct CompressedAlignment {
+    int n_leaves = 0, n_states = 0;
+    int64_t n_sites = 0;
+    std::vector<uint8_t> cols;          // [n_sites][n_leaves] byte image
+    std::vector<int64_t> site_to_pat;   // global pattern id per site
+    std::vector<int64_t> first_site;    // representative site per global pattern
+    std::vector<double> count;          // multiplicity per global pattern
+};
+
+void compress_alignment(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress, CompressedAlignment &ca)
 {
     if (!codes || n_leaves < 1 || n_sites < 0) fail(CRAB_ERR_ARG, "crab_set_alignment: bad arguments");
     if (n_states < 1 || n_states > NS - 1) fail(CRAB_ERR_ARG, "n_states must be in [1, 63], got " + std::to_string(n_states));
+    ca.n_leaves = n_leaves;
+    ca.n_states = n_states;
+    ca.n_sites = n_sites;
+    compress_patterns(codes, n_leaves, n_sites, n_states, compress, ca.cols, ca.site_to_pat, ca.first_site, ca.count);
+}
+
+// Uploads patterns [pat_begin, pat_end) of a compressed alignment to the engine's device.
+void upload_alignment(crab_engine *e, const CompressedAlignment &ca, int64_t pat_begin, int64_t pat_end)
+{
+    const int n_leaves = ca.n_leaves, n_states = ca.n_states;
     e->have_aln = false;
     e->n_states = n_states;
     e->aln_rows = n_leaves;
-    e->n_sites = n_sites;
-    std::vector<uint8_t> cols;
-    std::vector<int64_t> first_site;  // representative site per global pattern
-    std::vector<double> count;
-    compress_patterns(codes, n_leaves, n_sites, n_states, compress, cols, e->site_to_pat, first_site, count);
-    e->n_pat_total = (int64_t)first_site.size();
+    e->n_sites = ca.n_sites;
+    e->site_to_pat = ca.site_to_pat;
+    e->n_pat_total = (int64_t)ca.first_site.size();
     if (pat_end < 0 || pat_end > e->n_pat_total) pat_end = e->n_pat_total;
     if (pat_begin < 0) pat_begin = 0;
     if (pat_begin > pat_end) pat_begin = pat_end;
@@ -682,9 +869,9 @@ void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t 
     std::vector<uint8_t> img((size_t)n_leaves * e->n_pat_pad, (uint8_t)n_states);
     e->weights.assign(e->n_pat_pad, 0.0);
     for (int64_t p = 0; p < e->n_pat; ++p) {
-        const uint8_t *col = &cols[(size_t)first_site[pat_begin + p] * n_leaves];
+        const uint8_t *col = &ca.cols[(size_t)ca.first_site[pat_begin + p] * n_leaves];
         for (int r = 0; r < n_leaves; ++r) img[(size_t)r * e->n_pat_pad + p] = col[r];
-        e->weights[p] = count[pat_begin + p];
+        e->weights[p] = ca.count[pat_begin + p];
     }
     HIP_CHECK(hipSetDevice(e->device));
     e->d_codes.ensure(img.size());
@@ -693,6 +880,15 @@ void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t 
     HIP_CHECK(hipMemcpyAsync(e->d_weights.p, e->weights.data(), e->n_pat_pad * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
     e->have_aln = true;
+}
+
+void load_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
+                    int64_t pat_begin, int64_t pat_end)
+{
+    e->have_aln = false;
+    CompressedAlignment ca;
+    compress_alignment(codes, n_leaves, n_sites, n_states, compress, ca);
+    upload_alignment(e, ca, pat_begin, pat_end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -816,7 +1012,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     double *h_eig = e->h_eig.p;
     std::vector<char> ok(todo.size(), 1);
     std::vector<double> Qbuilt(by_params ? todo.size() * (size_t)n * n : 0);
-    parallel_for((int)todo.size(), [&](int j) {
+    auto decompose_one = [&](int j) {
         const int i = uniq_src[todo[j]];
         const double *Qi = Q + (size_t)i * n * n;
         if (by_params) {
@@ -825,7 +1021,22 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             Qi = dst;
         }
         ok[j] = spectral_decompose(n, Qi, pi, h_eig + (size_t)j * EIG_STRIDE) ? 1 : 0;
-    });
+    };
+    if (e->shared_eig) {   // a shard of a multi-device handle: every shard needs this matrix, one of them decomposes it
+        SharedEigCache *sc = e->shared_eig;
+        parallel_for((int)todo.size(), [&](int j) {
+            const int i = uniq_src[todo[j]];
+            ok[j] = sc->get(qhash[i], by_params, by_params ? pl.kw[i].first : 0.0, by_params ? pl.kw[i].second : 0.0,
+                            by_params ? nullptr : Q + (size_t)i * n * n, pi, n, h_eig + (size_t)j * EIG_STRIDE, [&](double *) {
+                                decompose_one(j);
+                                return ok[j] != 0;
+                            })
+                        ? 1
+                        : 0;
+        });
+    } else {
+        parallel_for((int)todo.size(), decompose_one);
+    }
     for (size_t j = 0; j < todo.size(); ++j)
         if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(uniq_src[todo[j]]));
     std::vector<int> new_slots;
@@ -920,7 +1131,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
     e->d_P.ensure((size_t)M * P_ELEMS);
     const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
-    const int grid = prune_grid_size(n_tiles * pl.K);
+    const int grid = prune_grid_size(n_tiles * pl.K, e->device);
     e->d_stack.ensure(prune_stack_doubles(grid, e->max_depth));
     e->d_stack_e.ensure(prune_stack_ints(grid, e->max_depth));
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
@@ -1121,6 +1332,49 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// multi-device handles: one crab_engine that owns several GPUs of one process (crab_create_multi)
+// ---------------------------------------------------------------------------------------------
+// Site patterns are independent (likelihood.rs:176-195 never mixes alignment rows): shard r holds a tile-aligned slice of
+// the compressed pattern list on its own device, with its own stream and host thread, and every transition matrix.
+// A call on the handle runs on all shards at once; log-likelihoods are added in shard order on the host (fixed order:
+// bit-identical from run to run), per-site outputs are written by the shard that owns the site.
+template <typename F>
+int fan_out(crab_engine *e, F &&call)   // call(shard, r) -> status; returns the first failure, message copied to e->err
+{
+    const int N = (int)e->shards.size();
+    std::vector<int> rc(N, CRAB_OK);
+    for (int r = 1; r < N; ++r) e->workers->post(r - 1, [&, r] { rc[r] = call(e->shards[r], r); });
+    rc[0] = call(e->shards[0], 0);
+    for (int r = 1; r < N; ++r) e->workers->wait(r - 1);
+    for (int r = 0; r < N; ++r)
+        if (rc[r] != CRAB_OK) {
+            e->err = "device " + std::to_string(e->shards[r]->device) + " (shard " + std::to_string(r) + "): " + e->shards[r]->err;
+            return rc[r];
+        }
+    return CRAB_OK;
+}
+
+// B log-likelihoods per shard, added in shard order
+template <typename F>
+int multi_sum(crab_engine *e, int B, double *lnL, F &&call)   // call(shard, partial lnL [B]) -> status
+{
+    if (B < 1 || !lnL) {
+        e->err = "bad arguments";
+        return CRAB_ERR_ARG;
+    }
+    const int N = (int)e->shards.size();
+    std::vector<double> part((size_t)N * B, 0.0);
+    const int rc = fan_out(e, [&](crab_engine *sh, int r) { return call(sh, part.data() + (size_t)r * B); });
+    if (rc != CRAB_OK) return rc;
+    for (int b = 0; b < B; ++b) {
+        double total = 0.0;
+        for (int r = 0; r < N; ++r) total += part[(size_t)r * B + b];
+        lnL[b] = total;
+    }
+    return CRAB_OK;
+}
+
 void plan_site_classes(crab_engine *e, EvalPlan &pl, int K, const double *Q, const double *t)
 {
     const int nn = e->n_nodes;
@@ -1257,6 +1511,33 @@ int crab_create(int device, crab_engine **out)
     return rc;
 }
 
+int crab_create_multi(const int *devices, int n_devices, crab_engine **out)
+{
+    if (!out) return CRAB_ERR_ARG;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) {
+        g_last_error = "crab_create_multi: need 1 to 64 device ordinals";
+        return CRAB_ERR_ARG;
+    }
+    std::unique_ptr<crab_engine> e(new (std::nothrow) crab_engine());
+    if (!e) return CRAB_ERR_DEVICE;
+    e->device = devices[0];
+    for (int r = 0; r < n_devices; ++r) {
+        crab_engine *sh = nullptr;
+        const int rc = crab_create(devices[r], &sh);   // leaves its message in g_last_error
+        if (rc != CRAB_OK) return rc;                  // e's destructor frees the shards made so far
+        e->shards.push_back(sh);
+    }
+    e->shared_eig_owner.reset(new SharedEigCache());
+    for (crab_engine *sh : e->shards) sh->shared_eig = e->shared_eig_owner.get();
+    e->workers.reset(new ShardWorkers());
+    e->workers->start(n_devices - 1);
+    *out = e.release();
+    return CRAB_OK;
+}
+
+int crab_n_devices(const crab_engine *e) { return e ? (e->is_multi() ? (int)e->shards.size() : 1) : 0; }
+
 void crab_destroy(crab_engine *e) { delete e; }
 
 const char *crab_last_error(const crab_engine *e) { return e ? e->err.c_str() : g_last_error.c_str(); }
@@ -1265,6 +1546,13 @@ int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const in
                   int n_leaves)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {
+        const int rc = fan_out(e, [&](crab_engine *sh, int) { return crab_set_tree(sh, n_nodes, node_ids, parents, leaf_node_ids, n_leaves); });
+        e->have_tree = rc == CRAB_OK;
+        e->n_nodes = e->shards[0]->n_nodes;
+        e->root = e->shards[0]->root;
+        return rc;
+    }
     return guarded(e, [&] {
         e->have_tree = false;
         e->dev_ops.clear();
@@ -1277,6 +1565,32 @@ int crab_set_alignment(crab_engine *e, const int32_t *codes, int n_leaves, int64
                        int64_t pattern_begin, int64_t pattern_end)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {
+        // compress once, then every shard uploads its own tile-aligned slice of [pattern_begin, pattern_end)
+        CompressedAlignment ca;
+        e->have_aln = false;
+        int rc = guarded(e, [&] { compress_alignment(codes, n_leaves, n_sites, n_states, compress, ca); });
+        if (rc != CRAB_OK) return rc;
+        const int64_t total = (int64_t)ca.first_site.size();
+        int64_t lo = std::max<int64_t>(0, pattern_begin), hi = (pattern_end < 0 || pattern_end > total) ? total : pattern_end;
+        if (lo > hi) lo = hi;
+        const int N = (int)e->shards.size();
+        const int64_t tile = prune_tile_width(), tiles = (hi - lo + tile - 1) / tile, per = (tiles + N - 1) / N;
+        rc = fan_out(e, [&](crab_engine *sh, int r) {
+            const int64_t b = std::min(hi, lo + (int64_t)r * per * tile), en = std::min(hi, lo + (int64_t)(r + 1) * per * tile);
+            return guarded(sh, [&] { upload_alignment(sh, ca, b, en); });
+        });
+        if (rc != CRAB_OK) return rc;
+        e->n_states = n_states;
+        e->aln_rows = n_leaves;
+        e->n_sites = n_sites;
+        e->n_pat_total = total;
+        e->pat_begin = lo;
+        e->pat_end = hi;
+        e->n_pat = hi - lo;
+        e->have_aln = true;
+        return CRAB_OK;
+    }
     return guarded(e, [&] { load_alignment(e, codes, n_leaves, n_sites, n_states, compress, pattern_begin, pattern_end); });
 }
 
@@ -1288,6 +1602,10 @@ int crab_eval_site_classes(crab_engine *e, int K, const double *Q, const double 
                            const double *branch_lengths, unsigned flags, double *lnL, double *site_lnl)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, 1, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_site_classes(sh, K, Q, proportions, pi, branch_lengths, flags, part, site_lnl);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (K < 1 || !Q || !proportions || !pi || !branch_lengths || !lnL) fail(CRAB_ERR_ARG, "crab_eval_site_classes: bad arguments");
@@ -1303,6 +1621,10 @@ int crab_eval_site_classes_batch(crab_engine *e, int B, int K, const double *Q, 
                                  const double *branch_lengths, unsigned flags, double *lnL)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, B, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_site_classes_batch(sh, B, K, Q, proportions, pi, branch_lengths, flags, part);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (B < 1 || K < 1 || !Q || !proportions || !pi || !branch_lengths || !lnL)
@@ -1335,6 +1657,8 @@ int crab_eval_site_lnl_by_class(crab_engine *e, int K, const double *Q, const do
                                 unsigned flags, double *out)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())   // every shard writes the rows of its own sites
+        return fan_out(e, [&](crab_engine *sh, int) { return crab_eval_site_lnl_by_class(sh, K, Q, pi, branch_lengths, flags, out); });
     return guarded(e, [&] {
         check_ready(e);
         if (K < 1 || !Q || !pi || !branch_lengths || !out) fail(CRAB_ERR_ARG, "crab_eval_site_lnl_by_class: bad arguments");
@@ -1350,6 +1674,46 @@ int crab_eval_beb_grid(crab_engine *e, int K, const double *Q, const double *pi,
                        const int32_t *cols, const double *props, unsigned flags, double *posteriors, double *lnfx, double *ln_fx)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {
+        // f(X | grid point) is a product over all sites: the shards' per-grid-point sums are added in shard order, then
+        // every shard integrates the posteriors of its own sites (the protocol of CRAB_FLAG_BEB_PARTIAL / _GIVEN_LNFX)
+        const bool partial = flags & CRAB_FLAG_BEB_PARTIAL, given = flags & CRAB_FLAG_BEB_GIVEN_LNFX;
+        if (G < 1 || (partial && given) || ((partial || given) && !lnfx) || (!posteriors && !partial)) {
+            e->err = "crab_eval_beb_grid: bad arguments";
+            return CRAB_ERR_ARG;
+        }
+        if (!partial && !given && (e->pat_begin != 0 || e->pat_end != e->n_pat_total)) {
+            e->err = "crab_eval_beb_grid needs the whole alignment on one handle, or the two-call protocol of "
+                     "CRAB_FLAG_BEB_PARTIAL / CRAB_FLAG_BEB_GIVEN_LNFX";
+            return CRAB_ERR_STATE;
+        }
+        const int N = (int)e->shards.size();
+        std::vector<double> total(G, 0.0);
+        if (!given) {
+            std::vector<double> part((size_t)N * G, 0.0);
+            const int rc = fan_out(e, [&](crab_engine *sh, int r) {
+                return crab_eval_beb_grid(sh, K, Q, pi, branch_lengths, G, n_mix, cols, props, CRAB_FLAG_BEB_PARTIAL, nullptr,
+                                          part.data() + (size_t)r * G, nullptr);
+            });
+            if (rc != CRAB_OK) return rc;
+            for (int g = 0; g < G; ++g)
+                for (int r = 0; r < N; ++r) total[g] += part[(size_t)r * G + g];
+            if (lnfx) std::copy(total.begin(), total.end(), lnfx);
+            if (partial) {
+                if (ln_fx) *ln_fx = 0.0;
+                return CRAB_OK;
+            }
+        } else {
+            std::copy(lnfx, lnfx + G, total.begin());
+        }
+        std::vector<double> lf(N, 0.0);
+        const int rc = fan_out(e, [&](crab_engine *sh, int r) {
+            return crab_eval_beb_grid(sh, K, Q, pi, branch_lengths, G, n_mix, cols, props, CRAB_FLAG_BEB_GIVEN_LNFX, posteriors,
+                                      total.data(), &lf[r]);
+        });
+        if (rc == CRAB_OK && ln_fx) *ln_fx = lf[0];
+        return rc;
+    }
     return guarded(e, [&] {
         check_ready(e);
         const bool partial = flags & CRAB_FLAG_BEB_PARTIAL, given = flags & CRAB_FLAG_BEB_GIVEN_LNFX;
@@ -1385,6 +1749,11 @@ int crab_eval_branch_site(crab_engine *e, const double *Q3, double qfactor_back,
 {
     (void)flags;
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, 1, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_branch_site(sh, Q3, qfactor_back, qfactor_fore, omega0, omega2, site_class_freqs, pi, branch_lengths, labels,
+                                         n_labels, flags, part, site_lnl);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (!Q3 || !site_class_freqs || !pi || !branch_lengths || !labels || !lnL) fail(CRAB_ERR_ARG, "crab_eval_branch_site: bad arguments");
@@ -1427,6 +1796,10 @@ int crab_eval_branch(crab_engine *e, int n_q, const double *Q, const double *pi,
                      int n_branch_lengths, unsigned flags, double *lnL, double *site_lnl)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, 1, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_branch(sh, n_q, Q, pi, branch_lengths, n_branch_lengths, flags, part, site_lnl);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (!Q || !pi || !branch_lengths || !lnL) fail(CRAB_ERR_ARG, "crab_eval_branch: bad arguments");
@@ -1459,6 +1832,18 @@ int crab_eval_branch(crab_engine *e, int n_q, const double *Q, const double *pi,
 int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kernel_ms, double *host_eigen_ms)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {   // the shards run side by side: the slowest one is the call
+        double d = 0, p = 0, h = 0;
+        for (const crab_engine *sh : e->shards) {
+            d = std::max(d, sh->last_device_ms);
+            p = std::max(p, sh->last_prune_ms);
+            h = std::max(h, sh->last_eigen_ms);
+        }
+        if (device_ms) *device_ms = d;
+        if (prune_kernel_ms) *prune_kernel_ms = p;
+        if (host_eigen_ms) *host_eigen_ms = h;
+        return CRAB_OK;
+    }
     if (device_ms) *device_ms = e->last_device_ms;
     if (prune_kernel_ms) *prune_kernel_ms = e->last_prune_ms;
     if (host_eigen_ms) *host_eigen_ms = e->last_eigen_ms;
@@ -1468,6 +1853,11 @@ int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kern
 int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {   // every shard built the same matrices
+        const int rc = crab_export_transition_matrices(e->shards[0], k, P_out);
+        if (rc != CRAB_OK) e->err = e->shards[0]->err;
+        return rc;
+    }
     return guarded(e, [&] {
         if (!P_out || k < 0 || k >= e->last_K || e->last_M <= 0) fail(CRAB_ERR_STATE, "no evaluation to export from, or class out of range");
         const int n = e->n_states, nn = e->n_nodes;
@@ -1486,6 +1876,18 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
 int crab_eig_pool_stats(const crab_engine *e, int64_t *hits, int64_t *misses, int64_t *resident)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {   // sums over the shards' device-resident pools
+        int64_t h = 0, m = 0, r = 0;
+        for (const crab_engine *sh : e->shards) {
+            int64_t a = 0, b = 0, c = 0;
+            crab_eig_pool_stats(sh, &a, &b, &c);
+            h += a, m += b, r += c;
+        }
+        if (hits) *hits = h;
+        if (misses) *misses = m;
+        if (resident) *resident = r;
+        return CRAB_OK;
+    }
     if (hits) *hits = e->eig_hits;
     if (misses) *misses = e->eig_misses;
     if (resident) {
@@ -1499,6 +1901,13 @@ int crab_eig_pool_stats(const crab_engine *e, int64_t *hits, int64_t *misses, in
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi()) {
+        int64_t d = 0, g = 0;
+        for (const crab_engine *sh : e->shards) d += sh->last_dense, g += sh->last_gather;
+        if (dense_updates) *dense_updates = d;
+        if (gather_updates) *gather_updates = g;
+        return CRAB_OK;
+    }
     if (dense_updates) *dense_updates = e->last_dense;
     if (gather_updates) *gather_updates = e->last_gather;
     return CRAB_OK;
@@ -1790,6 +2199,10 @@ int crab_eval_codon_site_classes(crab_engine *e, int B, int K, const double *kap
                                  const double *pi, const double *branch_lengths, unsigned flags, double *lnL)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, B, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_codon_site_classes(sh, B, K, kappa, omegas, proportions, pi, branch_lengths, flags, part);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (B < 1 || K < 1 || !kappa || !omegas || !proportions || !pi || !branch_lengths || !lnL)
@@ -1809,6 +2222,10 @@ int crab_eval_codon_class_posteriors(crab_engine *e, int B, int K, const double 
 {
     (void)flags;
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())   // every shard writes the rows of its own sites
+        return fan_out(e, [&](crab_engine *sh, int) {
+            return crab_eval_codon_class_posteriors(sh, B, K, kappa, omegas, proportions, weights, pi, branch_lengths, flags, posteriors);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (B < 1 || K < 1 || !kappa || !omegas || !proportions || !weights || !pi || !branch_lengths || !posteriors)
@@ -1828,6 +2245,10 @@ int crab_eval_codon_branch(crab_engine *e, int B, const double *kappa, const dou
                            const double *branch_lengths, unsigned flags, double *lnL)
 {
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, B, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_codon_branch(sh, B, kappa, omega_per_node, pi, branch_lengths, flags, part);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (B < 1 || !kappa || !omega_per_node || !pi || !branch_lengths || !lnL) fail(CRAB_ERR_ARG, "crab_eval_codon_branch: bad arguments");
@@ -1870,6 +2291,10 @@ int crab_eval_codon_branch_site(crab_engine *e, int B, const double *kappa, cons
 {
     (void)flags;
     if (!e) return CRAB_ERR_ARG;
+    if (e->is_multi())
+        return multi_sum(e, B, lnL, [&](crab_engine *sh, double *part) {
+            return crab_eval_codon_branch_site(sh, B, kappa, omega0, omega2, p0, p1, pi, branch_lengths, labels, n_labels, flags, part);
+        });
     return guarded(e, [&] {
         check_ready(e);
         if (B < 1 || !kappa || !omega0 || !omega2 || !p0 || !p1 || !pi || !branch_lengths || !labels || !lnL)
@@ -1972,6 +2397,26 @@ uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
 }
 namespace {
 
+// device = -1 in the one-shot functions: the device list of the environment variable CRAB_DEVICES ("0,1,2,3": one
+// multi-device handle over those GPUs; unset or empty: device 0)
+std::vector<int> devices_from_env()
+{
+    std::vector<int> out;
+    if (const char *sv = std::getenv("CRAB_DEVICES")) {
+        const char *p = sv;
+        while (*p) {
+            char *end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            out.push_back((int)v);
+            p = end;
+            while (*p == ',' || *p == ' ') ++p;
+        }
+    }
+    if (out.empty()) out.push_back(0);
+    return out;
+}
+
 // Returns a cached engine for this (alignment, tree), creating it on first sight.  The caller holds g_cache_mutex.
 crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents,
                            const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_ids, int *status)
@@ -1981,6 +2426,11 @@ crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t 
         g_last_error = "bad arguments";
         *status = CRAB_ERR_ARG;
         return nullptr;
+    }
+    std::vector<int> devs;
+    if (device < 0) {
+        devs = devices_from_env();
+        device = -1 - (int)(hash_words(devs.data(), devs.size() * sizeof(int), 5) & 0x3fffffff);   // one key per device list
     }
     CacheKey key{device, n_leaves, n_sites, n_states, 0, 0};
     // the stateless boundary hands the alignment over on every call (4 MB at C2): hash it in 256 KiB chunks on the
@@ -2009,7 +2459,7 @@ crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t 
             return g_cache.front().engine;
         }
     crab_engine *e = nullptr;
-    int rc = crab_create(device, &e);
+    int rc = devs.size() > 1 ? crab_create_multi(devs.data(), (int)devs.size(), &e) : crab_create(devs.empty() ? device : devs[0], &e);
     if (rc == CRAB_OK) {
         rc = crab_set_tree(e, n_nodes, node_ids, parents, leaf_ids, n_leaves);
         if (rc == CRAB_OK) rc = crab_set_alignment(e, codes, n_leaves, n_sites, n_states, 1, 0, -1);

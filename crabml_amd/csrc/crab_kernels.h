@@ -117,8 +117,8 @@ int prune_reg_stack_slots();
 bool prune_has_prefetch();
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();
-// Number of workgroups launch_prune will use for n_work = tiles*K work items (persistent grid).
-int prune_grid_size(int64_t n_work);
+// Number of workgroups launch_prune will use for n_work = tiles*K work items on HIP device `device` (persistent grid).
+int prune_grid_size(int64_t n_work, int device);
 // Bytes of stack / stack_e needed for a grid of `grid` workgroups and `max_depth` slots.
 size_t prune_stack_doubles(int grid, int max_depth);
 size_t prune_stack_ints(int grid, int max_depth);

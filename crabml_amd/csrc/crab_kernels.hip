@@ -905,13 +905,11 @@ int prune_tile_width() { return 64 * chosen_nt(); }
 int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }
 bool prune_has_prefetch() { return chosen_nt() == 1 ? Plan<1>::HAS_PRE : Plan<2>::HAS_PRE; }
 
-int prune_grid_size(int64_t n_work)
+int prune_grid_size(int64_t n_work, int device)
 {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    // the engine's device, not the thread's current one: one process may hold engines on several GPUs
+    int cus = 256, v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) cus = v;
     const int64_t cap = (int64_t)cus * blocks_per_cu();
     const int64_t want = ((n_work + N_XCD - 1) / N_XCD) * N_XCD;  // a multiple of N_XCD: see prune_body
     return (int)(want < cap ? want : cap);

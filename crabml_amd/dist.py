@@ -79,14 +79,16 @@ class ShardedLikelihood:
 
 
 def sharded_engine(codes, parents, leaf_node_ids, rank: int, world_size: int, device: int | None = None, n_states: int = 61):
-    """An Engine holding rank's slice of the alignment's patterns (needs a GPU)."""
+    """An Engine holding rank's slice of the alignment's patterns (needs a GPU).  ``device`` defaults to the
+    process's LOCAL_RANK (the global rank is not a device ordinal on a multi-node job)."""
+    import os
     from .engine import Engine, compress_patterns
-    from ._lib import load
-    import ctypes as C
     _, w, _ = compress_patterns(codes, n_states)
     width = 128
     begin, end = pattern_slices(len(w), world_size, width)[rank]
-    eng = Engine(rank if device is None else device)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", rank))
+    eng = Engine(device)
     eng.set_tree(parents, leaf_node_ids)
     eng.set_alignment(codes, n_states=n_states, compress=True, pattern_begin=begin, pattern_end=end)
     return eng

@@ -19,11 +19,19 @@ def tree_arrays(tree_structure):
 
 
 class Engine:
-    def __init__(self, device: int = 0):
+    """``Engine(0)``: one GPU.  ``Engine([0, 1, 2, 3])``: one handle over several GPUs of this process
+    (crab_create_multi): patterns sliced over them, every evaluation on all of them at once, same methods."""
+
+    def __init__(self, device=0):
         self._lib = L.load()
         self._h = L.vp()
-        L.check(self._lib.crab_create(int(device), C.byref(self._h)))
-        self.device = int(device)
+        if np.ndim(device) == 0:
+            L.check(self._lib.crab_create(int(device), C.byref(self._h)))
+            self.device = int(device)
+        else:
+            devs, dp_ = L.i32(list(device))
+            L.check(self._lib.crab_create_multi(dp_, len(devs), C.byref(self._h)))
+            self.device = [int(d) for d in devs]
         self.n_nodes = 0
         self.n_states = 0
         self.n_sites = 0
@@ -72,6 +80,10 @@ class Engine:
                                                  1 if compress else 0, int(pattern_begin), int(pattern_end)))
         self.n_states = int(n_states)
         self.n_sites = codes_.shape[1]
+
+    @property
+    def n_devices(self) -> int:
+        return int(self._lib.crab_n_devices(self._h))
 
     @property
     def n_patterns(self) -> int:

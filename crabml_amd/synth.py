@@ -42,11 +42,17 @@ def random_tree(n_taxa: int, rng, mean_branch: float):
     return parent, bl
 
 
-def _transition_matrix(Q, pi, t):
+def _transition_matrix(Q, pi, t, eig_cache=None):
     sq = np.sqrt(pi)
-    S = Q * sq[:, None] / sq[None, :]
-    S = 0.5 * (S + S.T)
-    lam, V = np.linalg.eigh(S)
+    key = (Q.__array_interface__["data"][0], Q.shape)   # the class matrices are views of one stack: same memory, same matrix
+    if eig_cache is not None and key in eig_cache:
+        lam, V = eig_cache[key]
+    else:
+        S = Q * sq[:, None] / sq[None, :]
+        S = 0.5 * (S + S.T)
+        lam, V = np.linalg.eigh(S)
+        if eig_cache is not None:
+            eig_cache[key] = (lam, V)
     P = (V * np.exp(lam * t)) @ V.T
     P = P * sq[None, :] / sq[:, None]
     P = np.clip(P, 0.0, None)
@@ -54,14 +60,17 @@ def _transition_matrix(Q, pi, t):
 
 
 def _sample_children(P, parent_states, rng):
+    """Child state per site: inverse-CDF draw from row parent_state of P (the number of cumulative sums below u)."""
     cum = np.cumsum(P, axis=1)
     cum[:, -1] = 1.0
     u = rng.random(parent_states.shape[0])
     out = np.empty_like(parent_states)
-    step = 1 << 16
-    for s in range(0, len(parent_states), step):
-        rows = cum[parent_states[s:s + step]]
-        out[s:s + step] = (u[s:s + step, None] > rows).sum(axis=1)
+    order = np.argsort(parent_states, kind="stable")          # sites grouped by parent state: one searchsorted per row of P
+    bounds = np.searchsorted(parent_states[order], np.arange(P.shape[0] + 1))
+    for i in range(P.shape[0]):
+        idx = order[bounds[i]:bounds[i + 1]]
+        if len(idx):
+            out[idx] = np.searchsorted(cum[i], u[idx], side="left")
     return np.minimum(out, P.shape[0] - 1)
 
 
@@ -73,6 +82,7 @@ def evolve(parent, bl, pi, site_Q_of_node, site_class, n_sites, rng, gap_fractio
     states = np.zeros((n_nodes, n_sites), dtype=np.int64)
     states[root] = rng.choice(61, size=n_sites, p=pi)
     classes = np.unique(site_class)
+    eig_cache = {}   # one decomposition per rate matrix, not per (branch, class): 500 taxa x 50 000 codons in seconds
     class_sites = {int(k): np.flatnonzero(site_class == k) for k in classes}
     for v in range(n_nodes - 2, -1, -1):  # parents have larger ids than children
         p = parent[v]
@@ -80,7 +90,7 @@ def evolve(parent, bl, pi, site_Q_of_node, site_class, n_sites, rng, gap_fractio
         for k, idx in class_sites.items():
             qid, Q, teff = site_Q_of_node(v, k)
             if qid not in cache:
-                cache[qid] = _transition_matrix(Q, pi, teff)
+                cache[qid] = _transition_matrix(Q, pi, teff, eig_cache)
             states[v, idx] = _sample_children(cache[qid], states[p, idx], rng)
     codes = states[:n_taxa].astype(np.int32)
     if gap_fraction > 0:

@@ -64,6 +64,18 @@ typedef enum {
 /* ---- lifetime ------------------------------------------------------------ */
 /* device = HIP device ordinal (one engine per process/GPU is the intended use). */
 int crab_create(int device, crab_engine **out);
+/* One handle over several GPUs of this process (SURVEY 8(b) sketches crab_create(device_mask, ...); a list keeps the
+ * order, which fixes the summation order).  The unchanged crabML is ONE Python process that calls the FFI once per
+ * objective (core/likelihood_rust.py:226-288 -> lib.rs:146-191); with this handle that one call runs on every listed
+ * GPU: crab_set_alignment compresses the alignment once and gives shard r a tile-aligned slice of the pattern list on
+ * devices[r]; every crab_eval_* runs on all shards at once (one host thread and one stream per device, each rate
+ * matrix decomposed once and shared), log-likelihoods (one, or B for batched calls) are added in shard order on the
+ * host -- bit-identical from run to run -- and per-site outputs ([n_sites], [n_sites][K], BEB posteriors) are written by
+ * the shard that owns the site.  The handle is used like any other engine with every function below; a device may be
+ * listed more than once (several shards on one GPU).  n_devices in [1, 64]. */
+int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
+/* Shards behind a handle: 1 for crab_create, n_devices for crab_create_multi. */
+int crab_n_devices(const crab_engine *e);
 void crab_destroy(crab_engine *e);
 /* Message of the last failing call on `e` (or of the last failing call without a handle if e == NULL). */
 const char *crab_last_error(const crab_engine *e);
@@ -231,7 +243,9 @@ int crab_spectral_decompose(int n, const double *Q, const double *pi, double *U,
 int crab_host_pool_selftest(int callers, int n, int rounds);
 
 /* ---- one-shot forms with the argument lists of the PyO3 functions ------------- */
-/* Each looks up (or creates) a cached engine for (codes pointer, shape, checksum, tree) on `device`. */
+/* Each looks up (or creates) a cached engine for (codes pointer, shape, checksum, tree) on `device`.
+ * device = -1: the GPUs listed in the environment variable CRAB_DEVICES (comma-separated ordinals, e.g. "0,1,2,3,4,5,6,7";
+ * unset: device 0) through crab_create_multi, so that one unchanged crabML process uses the whole node. */
 int crab_compute_log_likelihood(int device, int n, const double *q, const double *pi, int n_nodes,
                                 const int32_t *node_ids, const int32_t *parents, const double *branch_lengths,
                                 const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_node_ids,

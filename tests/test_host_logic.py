@@ -413,3 +413,21 @@ def test_host_worker_pool_serves_concurrent_callers():
     lib = _lib.load()
     for callers, n, rounds in ((1, 11, 50), (4, 11, 200), (16, 63, 100), (8, 1998, 5), (3, 2, 300)):
         _lib.check(lib.crab_host_pool_selftest(callers, n, rounds))
+
+
+def test_tree_rejects_a_repeated_node_id():
+    """tree_structure lists every node exactly once; a repeated id would leave another node without an entry."""
+    from crabml_amd.engine import compile_tree
+    with pytest.raises(ValueError, match="more than once"):
+        compile_tree([2, 2, -1], [0, 1], node_ids=[0, 0, 2])
+    ops, _ = compile_tree([2, 2, -1], [0, 1], node_ids=[1, 0, 2])
+    assert len(ops) == 2
+
+
+def test_shim_checks_the_number_of_leaf_node_ids():
+    """The C library reads one node id per alignment row: a shorter list must be refused before it gets there."""
+    from crabml_amd import crabml_rust as shim
+    c = load_case("lysozyme_m0")
+    ts = tree_structure(c["parent"])
+    with pytest.raises(ValueError, match="leaf_node_ids has 6 entries but sequences has 7 rows"):
+        shim.compute_log_likelihood(c["Q"][0], c["pi"], ts, c["branch_lengths"].tolist(), [], c["sequences"], list(range(6)))

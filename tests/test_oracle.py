@@ -226,3 +226,69 @@ def test_codon_q_builder(oracle):
     np.testing.assert_allclose(Q, build_codon_Q_matrix(2.0, 0.5, pi), rtol=1e-13, atol=1e-16)
     np.testing.assert_allclose(oracle.build_codon_q_matrix_py(3.1, 1.7, pi, 1.0), build_codon_Q_matrix(3.1, 1.7, pi, 1.0),
                                rtol=1e-13, atol=1e-16)
+
+
+# ---------------------------------------------------------------------------------------------
+# the tail of the per-site parity gate: three eigen routes against 60-digit arithmetic
+# (fixture tests/golden/parity_tail.npz, made by tests/golden/make_parity_tail.py in the build container)
+# ---------------------------------------------------------------------------------------------
+def _tail_case(name):
+    from crabml_amd import synth
+    if name == "c2":
+        c = synth.make_case("M8", 100, 10000, seed=2)
+        return c.Q, np.asarray(c.proportions), c.pi, np.asarray(c.parent), c.branch_lengths, c.codes, False
+    if name == "free_ratio_60":
+        c = synth.make_case("free-ratio", 60, 1500, seed=22)
+        return c.Q_per_node, np.array([1.0]), c.pi, np.asarray(c.parent), c.branch_lengths, c.codes, True
+    c = load_case({"lysin": "lysin_m2a_gaps", "synthetic_edge": "synthetic_edge"}[name])
+    return c["Q"], c["proportions"], c["pi"], c["parent"], c["branch_lengths"], c["sequences"], False
+
+
+@pytest.mark.parametrize("name", ["c2", "lysin", "synthetic_edge", "free_ratio_60"])
+def test_eigen_routes_against_60_digit_truth(oracle, name):
+    """The reference's LAPACK route (eigh + inverse, matrix.rs:41-67), the oracle's Jacobi route and the engine's
+    Householder + QL route, each followed by the oracle's pruning, against values computed at 60 decimal digits, on the
+    sites where they differ most plus control sites.  (1) Every route's P(t) entries lie within EPS_P / 2 of the truth,
+    over every matrix of the case: the premise of util.eigen_route_bound.  (2) All three routes AND the truth lie within
+    that one per-site bound of each other: where the plain 1e-10 gate cannot hold for two correct evaluations, the
+    bound says by how much, and nothing is farther out than it allows.  (3) The engine's route is as close to the truth
+    as the reference's own."""
+    import os
+    from util import EPS_P, GOLDEN, eigen_route_bound
+    z = np.load(os.path.join(GOLDEN, "parity_tail.npz"), allow_pickle=False)
+    routes = [str(r) for r in z[f"{name}__routes"]]
+    assert routes == ["lapack", "jacobi", "ql"]
+    assert z[f"{name}__p_abs_err"].max() <= 0.5 * EPS_P                                    # (1)
+    sites, truth = z[f"{name}__sites"], z[f"{name}__truth"]
+    lnf = {r: z[f"{name}__lnf_{r}"] for r in routes}
+    Q, props, pi, parent, bl, codes, per_node = _tail_case(name)
+    ts, leaf = tree_structure(parent), np.arange(codes.shape[0], dtype=np.int32)
+    K = 1 if per_node else len(Q)
+    P = np.zeros((K, len(parent), len(pi), len(pi)))
+    for k in range(K):
+        for v in range(len(parent)):
+            if per_node or v == 0:
+                U, lam, Ui = oracle.cached_q(Q[v] if per_node else Q[k], pi)
+            P[k, v] = (U * np.exp(lam * (0.0 if parent[v] < 0 else bl[v]))[None, :]) @ Ui
+    sub = np.ascontiguousarray(codes[:, sites])
+
+    def mix(x):
+        x = np.maximum(x, np.log(1e-300))
+        with np.errstate(divide="ignore"):
+            x = x + np.log(props)[None, :]
+        mx = x.max(axis=1)
+        return mx + np.log(np.exp(x - mx[:, None]).sum(axis=1))
+
+    centre = mix(oracle.site_lnf_from_transition_matrices(P, pi, ts, sub, leaf))
+    bound = eigen_route_bound(oracle, P, pi, ts, sub, leaf, mix)
+    slack = 1e-12 * np.maximum(np.abs(truth), 1e-3)                                        # fp64 pruning itself
+    assert np.all(np.abs(centre - lnf["jacobi"]) <= bound + slack)      # same decomposition, numpy's product instead of the C loop's
+    for r in routes:
+        assert np.all(np.abs(lnf[r] - truth) <= bound + slack), r                          # (2)
+    den = np.maximum(np.abs(truth), 1e-3)
+    err = {r: (np.abs(lnf[r] - truth) / den).max() for r in routes}
+    assert err["ql"] <= max(1.25 * err["lapack"], SITE_RTOL)                               # (3)
+    n_tail = int(z[f"{name}__n_tail"])
+    if n_tail < len(sites):                                                                # control sites: all routes far inside 1e-10
+        for r in routes:
+            assert (np.abs(lnf[r] - truth) / den)[n_tail:].max() <= 0.01 * SITE_RTOL

@@ -82,3 +82,29 @@ def emulate_program(ops, P_of_node, codes, pi, n_states=61):
             cur = prod
     assert not stack, "stack not empty at the end of the program"
     return cur @ pi
+
+
+# -----------------------------------------------------------------------------------------------
+# how far apart may two correct evaluations of one site be?
+# -----------------------------------------------------------------------------------------------
+# Every eigen route to P(t) = exp(Qt) -- the reference's LAPACK eigh + inverse, the oracle's Jacobi, the engine's
+# Householder + QL with one re-orthogonalisation step -- leaves an ABSOLUTE error of a few 1e-16 ... 1e-15 on each entry
+# of P.  tests/golden/parity_tail.npz (made by make_parity_tail.py against 60-digit arithmetic) records the largest
+# such error of each route over every matrix of four cases: none exceeds 5e-15; tests/test_oracle.py asserts
+# EPS_P from the fixture.  Two routes therefore differ by at most 2 EPS_P per entry.
+EPS_P = 1e-14
+
+
+def eigen_route_bound(oracle, P, pi, ts, codes, leaf, mix, naive=False):
+    """Per-site bound on |ln f(P') - ln f(P'')| over all families P', P'' of transition matrices within 2 EPS_P of P
+    entry by entry.  The site likelihood is a polynomial with non-negative coefficients in the entries of the P's
+    (products and sums of non-negative numbers only), hence monotone in every entry: both values lie between the
+    likelihood of P - 2 EPS_P (floored at 0) and that of P + 2 EPS_P.  P: [K][n_nodes][n][n]; mix maps the [S, K]
+    table of ln f_{k,s} to per-site ln f (monotone too).  On ordinary sites the bound is ~1e-12; it grows exactly where
+    a site leans on entries of P that are themselves tiny, which is where two eigensolvers legitimately disagree
+    (+inf where the floored matrices make the site impossible: such a site is decided by rounding noise alone)."""
+    P = np.asarray(P)
+    lo = mix(oracle.site_lnf_from_transition_matrices(np.maximum(P - 2 * EPS_P, 0.0), pi, ts, codes, leaf, naive=naive))
+    hi = mix(oracle.site_lnf_from_transition_matrices(P + 2 * EPS_P, pi, ts, codes, leaf, naive=naive))
+    with np.errstate(invalid="ignore"):
+        return np.where(np.isfinite(lo), hi - lo, np.inf)
