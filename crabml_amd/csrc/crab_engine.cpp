@@ -399,6 +399,22 @@ struct TreeProgram {
     std::vector<TreeOp> ops;
     int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
     int64_t n_gemm_edges = 0, n_leaf_edges = 0;
+    // for path programs (partial updates): the ops that multiply a term into each node, in program order, and the op
+    // that crosses the branch above each internal node
+    std::vector<std::vector<int>> term_ops;
+    std::vector<int> gemm_op_of;
+    int n_save_slots = 0;
+};
+
+// What the kernel needs to know about one program besides its ops.
+struct ProgInfo {
+    int n_ops = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
+    int n_gemm = 0, n_leaf = 0;
+};
+// A path program: what changes when only the branch above `node` moves (see build_path_program).
+struct PathProgram {
+    std::vector<TreeOp> ops;
+    ProgInfo info;
 };
 
 struct crab_engine : TreeProgram {
@@ -411,6 +427,10 @@ struct crab_engine : TreeProgram {
     bool have_tree = false;
     std::vector<DevOp> dev_ops;  // [K][n_ops_pad] programs as last uploaded
     std::vector<int32_t> dev_pidx;  // the (class, node) -> matrix table they were resolved with
+    std::vector<int32_t> dev_vec_node;  // ... and which vectors of the batch run path programs (node moved, or -1)
+    int dev_n_whole = 0;                // programs in the first launch (whole walks); the rest are path programs
+    int64_t dev_gemm_per_pat = 0, dev_leaf_per_pat = 0;
+    std::unordered_map<int, PathProgram> path_programs;   // by moved node, built on first use
 
     // ---- alignment ----
     bool have_aln = false;
@@ -423,7 +443,10 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls;
+    DevBuf<ProgHdr> d_hdr;
+    DevBuf<char> d_save;
+    int last_n_path = 0;
     DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
     PinBuf<double> h_eig, h_small, h_out;
 
@@ -452,7 +475,7 @@ struct crab_engine : TreeProgram {
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
         h_eig.release(); h_small.release(); h_out.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -494,6 +517,81 @@ int guarded(crab_engine *e, F &&body)
 // ---------------------------------------------------------------------------------------------
 // tree -> program
 // ---------------------------------------------------------------------------------------------
+// Links the products of a program (a GEMM op's arg is the index of the next GEMM op, whose operand image it stages)
+// and lays down the leaf-edge prefetch schedule.  Used for the whole-tree program and for path programs alike.
+void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info)
+{
+    info = ProgInfo{};
+    info.n_ops = (int)ops.size();
+    for (const TreeOp &op : ops) {
+        info.n_gemm += op.kind == OP_GEMM;
+        info.n_leaf += op.kind == OP_LEAF;
+    }
+    // host program: a GEMM op's arg is the index of the next GEMM op (-1 none)
+    int next_gemm_op = -1;
+    for (int i = (int)ops.size() - 1; i >= 0; --i)
+        if (ops[i].kind == OP_GEMM) {
+            ops[i].arg = next_gemm_op;
+            next_gemm_op = i;
+        }
+    info.first_gemm_op = next_gemm_op;
+    // ---- pass 4: leaf-edge prefetch schedule.  A wave owns one prefetch tile G.  The columns of a leaf edge are
+    // requested into G at the first product (GEMM) after the previous leaf edge was consumed, so that the gather
+    // latency hides under MFMA work, or at the end of the op just before it when no product lies in between.
+    // When the two ops after a product are both leaf edges (a cherry, typically), the second one's columns are
+    // requested by the same product into the registers of its dying B operand, which is the landing tile of the
+    // ops that follow.  Codes are queued two leaf edges ahead. ----
+    std::vector<int> leaf_ops;
+    for (int i = 0; i < (int)ops.size(); ++i) {
+        TreeOp &op = ops[i];
+        op.pre_node = op.pre_node_b = -1;
+        op.pre_row2 = op.pre_row3 = -1;
+        op.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
+        if (op.kind == OP_LEAF) leaf_ops.push_back(i);
+    }
+    const int n_leaf = (int)leaf_ops.size();
+    auto leaf_row = [&](int k) { return k < n_leaf ? ops[leaf_ops[k]].arg : -1; };
+    info.first_leaf_row = leaf_row(0);
+    info.second_leaf_row = leaf_row(1);
+    info.third_leaf_row = leaf_row(2);
+    info.first_leaf_op = (n_leaf > 0 && leaf_ops[0] == 0) ? 0 : -1;
+    if (!prune_has_prefetch()) return;
+    const int reg_slots = prune_reg_stack_slots();
+    int li = 0;                                  // leaf_ops[li] = next leaf edge not yet consumed
+    int req = info.first_leaf_op == 0 ? 1 : 0;     // how many of the upcoming leaf edges have been requested (0..2)
+    for (int i = 0; i < (int)ops.size(); ++i) {
+        TreeOp &op = ops[i];
+        const bool next_is_leaf = i + 1 < (int)ops.size() && ops[i + 1].kind == OP_LEAF;
+        auto request_g = [&](int flag) {   // leaf li + req -> G (req must be 0)
+            op.flags |= flag;
+            op.pre_node = ops[leaf_ops[li]].node;
+            op.pre_row2 = leaf_row(li + 2);
+            req = 1;
+        };
+        if (op.kind == OP_LEAF) {
+            --req;
+            ++li;
+            if (req == 0 && next_is_leaf) request_g(F_PRE_LATE);
+        } else if (op.kind == OP_GEMM) {
+            const int head = li + req;  // leaf edge at the head of the code queue before this op
+            if (req == 0 && li < n_leaf) request_g(F_PRE_EARLY);
+            const bool global_pop = (op.flags & F_POP_MUL) && ((op.flags & F_POP_SAVED) || op.slot >= reg_slots);
+            if (req == 1 && next_is_leaf && li + 1 < n_leaf && leaf_ops[li + 1] == i + 2 && (ops[i + 2].flags & F_MUL_PROD) &&
+                !global_pop) {
+                op.flags |= F_PRE_DYING;
+                op.pre_node_b = ops[i + 2].node;
+                ops[i + 2].flags |= F_IN_LANDING;
+                req = 2;
+            }
+            // the requests of this op took 1 or 2 entries off the code queue: refill with the rows that follow
+            op.pre_row2 = leaf_row(head + 2);
+            op.pre_row3 = leaf_row(head + 3);
+        } else if (req == 0 && next_is_leaf) {
+            request_g(F_PRE_LATE);
+        }
+    }
+}
+
 void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_ids,
                 int n_leaves)
 {
@@ -662,101 +760,131 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
         for (TreeOp &op : e->ops)
             if ((op.flags & (F_PUSH | F_POP_MUL)) && op.slot >= 0 && op.slot < (int)rank.size()) op.slot = rank[op.slot];
     }
-    // host program: a GEMM op's arg is the index of the next GEMM op (-1 none)
-    int next_gemm_op = -1;
-    for (int i = (int)e->ops.size() - 1; i >= 0; --i)
-        if (e->ops[i].kind == OP_GEMM) {
-            e->ops[i].arg = next_gemm_op;
-            next_gemm_op = i;
-        }
-    e->first_gemm_op = next_gemm_op;
-    // ---- pass 4: leaf-edge prefetch schedule.  A wave owns one prefetch tile G.  The columns of a leaf edge are
-    // requested into G at the first product (GEMM) after the previous leaf edge was consumed, so that the gather
-    // latency hides under MFMA work, or at the end of the op just before it when no product lies in between.
-    // When the two ops after a product are both leaf edges (a cherry, typically), the second one's columns are
-    // requested by the same product into the registers of its dying B operand, which is the landing tile of the
-    // ops that follow.  Codes are queued two leaf edges ahead. ----
-    std::vector<int> leaf_ops;
+    // save slots of the partial-update path: three per internal edge (crab_kernels.h, "save area")
+    e->term_ops.assign(n_nodes, {});
+    e->gemm_op_of.assign(n_nodes, -1);
+    e->n_save_slots = 0;
     for (int i = 0; i < (int)e->ops.size(); ++i) {
         TreeOp &op = e->ops[i];
-        op.pre_node = op.pre_node_b = -1;
-        op.pre_row2 = op.pre_row3 = -1;
-        op.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
-        if (op.kind == OP_LEAF) leaf_ops.push_back(i);
+        op.sv = 0;
+        if (op.kind == OP_GEMM) {
+            op.sv = e->n_save_slots;
+            e->n_save_slots += 3;
+            e->gemm_op_of[op.node] = i;
+        }
+        if (op.kind == OP_GEMM || op.kind == OP_LEAF) e->term_ops[e->parent[op.node]].push_back(i);
     }
-    const int n_leaf = (int)leaf_ops.size();
-    auto leaf_row = [&](int k) { return k < n_leaf ? e->ops[leaf_ops[k]].arg : -1; };
-    e->first_leaf_row = leaf_row(0);
-    e->second_leaf_row = leaf_row(1);
-    e->third_leaf_row = leaf_row(2);
-    e->first_leaf_op = (n_leaf > 0 && leaf_ops[0] == 0) ? 0 : -1;
-    if (!prune_has_prefetch()) return;
-    const int reg_slots = prune_reg_stack_slots();
-    int li = 0;                                  // leaf_ops[li] = next leaf edge not yet consumed
-    int req = e->first_leaf_op == 0 ? 1 : 0;     // how many of the upcoming leaf edges have been requested (0..2)
-    for (int i = 0; i < (int)e->ops.size(); ++i) {
-        TreeOp &op = e->ops[i];
-        const bool next_is_leaf = i + 1 < (int)e->ops.size() && e->ops[i + 1].kind == OP_LEAF;
-        auto request_g = [&](int flag) {   // leaf li + req -> G (req must be 0)
-            op.flags |= flag;
-            op.pre_node = e->ops[leaf_ops[li]].node;
-            op.pre_row2 = leaf_row(li + 2);
-            req = 1;
-        };
-        if (op.kind == OP_LEAF) {
-            --req;
-            ++li;
-            if (req == 0 && next_is_leaf) request_g(F_PRE_LATE);
-        } else if (op.kind == OP_GEMM) {
-            const int head = li + req;  // leaf edge at the head of the code queue before this op
-            if (req == 0 && li < n_leaf) request_g(F_PRE_EARLY);
-            const bool global_pop = (op.flags & F_POP_MUL) && op.slot >= reg_slots;
-            if (req == 1 && next_is_leaf && li + 1 < n_leaf && leaf_ops[li + 1] == i + 2 && (e->ops[i + 2].flags & F_MUL_PROD) &&
-                !global_pop) {
-                op.flags |= F_PRE_DYING;
-                op.pre_node_b = e->ops[i + 2].node;
-                e->ops[i + 2].flags |= F_IN_LANDING;
-                req = 2;
-            }
-            // the requests of this op took 1 or 2 entries off the code queue: refill with the rows that follow
-            op.pre_row2 = leaf_row(head + 2);
-            op.pre_row3 = leaf_row(head + 3);
-        } else if (req == 0 && next_is_leaf) {
-            request_g(F_PRE_LATE);
+    ProgInfo info;
+    finalise_program(e->ops, info);
+    e->first_gemm_op = info.first_gemm_op;
+    e->first_leaf_row = info.first_leaf_row;
+    e->first_leaf_op = info.first_leaf_op;
+    e->second_leaf_row = info.second_leaf_row;
+    e->third_leaf_row = info.third_leaf_row;
+}
+
+// The program that recomputes the root's conditional likelihood when only the branch above `node` has changed, on the
+// tiles the base vector's walk saved (crab_kernels.h, "save area"): it starts from the saved operand of the moved edge
+// (or, for a leaf edge, from the parent's running product over its internal children) and climbs to the root; at each
+// node on the way the terms of the other children come from the save area (internal children) or are gathered again
+// (leaf children), multiplied in the order, with the rescaling points, of the whole-tree program -- so the result
+// carries the bits a whole walk of the perturbed vector would produce.
+void build_path_program(const TreeProgram *e, int node, PathProgram &out)
+{
+    const std::vector<TreeOp> &ops = e->ops;
+    auto plain = [&](int i) {   // the op as the whole-tree program has it, minus stack traffic and prefetch schedule
+        TreeOp o = ops[i];
+        o.flags &= ~(F_PUSH | F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
+        o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
+        return o;
+    };
+    auto load = [&](int slot, int flags) {
+        TreeOp o{};
+        o.kind = OP_LOAD;
+        o.node = -1;
+        o.flags = flags;
+        o.arg = 0;
+        o.slot = 0;
+        o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
+        o.sv = slot;
+        return o;
+    };
+    out.ops.clear();
+    int cur;
+    if (e->in_leaf_set[node]) {
+        const int p = e->parent[node];
+        const std::vector<int> &terms = e->term_ops[p];
+        int last_gemm = -1;
+        for (int t : terms)
+            if (ops[t].kind == OP_GEMM) last_gemm = t;
+        if (last_gemm >= 0) out.ops.push_back(load(ops[last_gemm].sv + 1, 0));   // running product over the internal children
+        for (int t : terms)
+            if (ops[t].kind == OP_LEAF) out.ops.push_back(plain(t));
+        cur = p;
+    } else {
+        out.ops.push_back(load(ops[e->gemm_op_of[node]].sv, 0));                   // L_node, the operand of the moved edge
+        cur = node;
+    }
+    while (cur != e->root) {
+        const int p = e->parent[cur];
+        const std::vector<int> &terms = e->term_ops[p];
+        size_t j = 0;
+        while (j < terms.size() && terms[j] != e->gemm_op_of[cur]) ++j;
+        TreeOp g = plain(terms[j]);
+        if (g.flags & F_POP_MUL) {      // the running product before this child is what the preceding sibling's op left
+            g.flags |= F_POP_SAVED;
+            g.slot = ops[terms[j - 1]].sv + 1;
         }
+        out.ops.push_back(g);
+        for (size_t i = j + 1; i < terms.size(); ++i) {
+            const TreeOp &o = ops[terms[i]];
+            if (o.kind == OP_GEMM)      // a later internal sibling: its message, multiplied in where its product was
+                out.ops.push_back(load(o.sv + 2, F_MUL_PROD | (o.flags & (F_RESCALE | F_FIN))));
+            else
+                out.ops.push_back(plain(terms[i]));
+        }
+        cur = p;
+    }
+    finalise_program(out.ops, out.info);
+}
+
+// Packs one program for the device: matrix indices (through pk, the program's node -> matrix table) instead of node
+// ids, and on each leaf edge the alignment row of the leaf edge after it (whose codes the kernel requests one edge
+// ahead).  `save`: GEMM ops store their tiles in the save area (the base vector of a batch with partial updates).
+void resolve_program(const std::vector<TreeOp> &ops, const int32_t *pk, bool save, DevOp *out)
+{
+    const size_t n_ops = ops.size();
+    int32_t row = -1;
+    std::vector<int32_t> next_leaf_row(n_ops, -1);
+    for (int i = (int)n_ops - 1; i >= 0; --i)
+        if (ops[i].kind == OP_LEAF) {
+            next_leaf_row[i] = row;
+            row = ops[i].arg;
+        }
+    for (size_t i = 0; i < n_ops; ++i) {
+        const TreeOp &op = ops[i];
+        DevOp d{};
+        const int flags = op.flags | ((save && op.kind == OP_GEMM) ? F_SAVE : 0);
+        d.w0 = op.kind | (flags << 2) | (op.slot << (2 + OP_FLAG_BITS));
+        d.pre_mat = op.pre_node >= 0 ? pk[op.pre_node] : -1;
+        d.pre_mat_b = op.pre_node_b >= 0 ? pk[op.pre_node_b] : -1;
+        d.pre_row2 = op.pre_row2;
+        d.pre_row3 = op.pre_row3;
+        d.mat = (op.kind == OP_CONST || op.kind == OP_LOAD) ? 0 : pk[op.node];
+        d.arg = op.kind == OP_GEMM ? (op.arg >= 0 ? pk[ops[op.arg].node] : -1) : op.kind == OP_LEAF ? next_leaf_row[i] : op.arg;
+        d.sv = op.sv;
+        out[i] = d;
     }
 }
 
-// Resolves the topology-only program into K packed device programs: matrix indices instead of node ids, and on
-// each leaf edge the alignment row of the leaf edge after it (whose codes the kernel requests one edge ahead).
+// Resolves the topology-only program into K packed device programs, one per class.
 void resolve_programs(const TreeProgram *e, int K, const std::vector<int32_t> &pidx, std::vector<DevOp> &out)
 {
-    const size_t n_ops = e->ops.size(), stride = (size_t)dev_ops_padded((int64_t)n_ops);
+    const size_t stride = (size_t)dev_ops_padded((int64_t)e->ops.size());
     DevOp filler{};
     filler.w0 = OP_CONST;
     out.assign((size_t)K * stride, filler);
-    std::vector<int32_t> next_leaf_row(n_ops, -1);
-    int32_t row = -1;
-    for (int i = (int)n_ops - 1; i >= 0; --i)
-        if (e->ops[i].kind == OP_LEAF) {
-            next_leaf_row[i] = row;
-            row = e->ops[i].arg;
-        }
-    for (int k = 0; k < K; ++k) {
-        const int32_t *pk = pidx.data() + (size_t)k * e->n_nodes;
-        for (size_t i = 0; i < n_ops; ++i) {
-            const TreeOp &op = e->ops[i];
-            DevOp d{};
-            d.w0 = op.kind | (op.flags << 2) | (op.slot << 11);
-            d.pre_mat = op.pre_node >= 0 ? pk[op.pre_node] : -1;
-            d.pre_mat_b = op.pre_node_b >= 0 ? pk[op.pre_node_b] : -1;
-            d.pre_row2 = op.pre_row2;
-            d.pre_row3 = op.pre_row3;
-            d.mat = op.kind == OP_CONST ? 0 : pk[op.node];
-            d.arg = op.kind == OP_GEMM ? (op.arg >= 0 ? pk[e->ops[op.arg].node] : -1) : op.kind == OP_LEAF ? next_leaf_row[i] : op.arg;
-            out[(size_t)k * stride + i] = d;
-        }
-    }
+    for (int k = 0; k < K; ++k) resolve_program(e->ops, pidx.data() + (size_t)k * e->n_nodes, false, out.data() + (size_t)k * stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -922,6 +1050,20 @@ struct EvalPlan {
     const double *post_weights = nullptr;   // [n_groups]: weighted class posteriors instead of a likelihood (kernel 4b)
     double *post_out = nullptr;             // out [n_sites][K / n_groups]
 };
+
+// CRAB_NO_PATH_UPDATES=1: whole walks for every vector of a batch (A/B timing, and the reference for the bit-equality tests)
+bool path_updates_disabled()
+{
+    const char *sv = std::getenv("CRAB_NO_PATH_UPDATES");
+    return sv && sv[0] && sv[0] != '0';
+}
+// Largest save area the partial-update path may allocate (CRAB_PATH_SAVE_GB, default 96 of the 288 GB)
+size_t path_save_limit_bytes()
+{
+    double gb = 96.0;
+    if (const char *sv = std::getenv("CRAB_PATH_SAVE_GB")) gb = std::atof(sv);
+    return gb > 0.0 ? (size_t)(gb * 1073741824.0) : 0;
+}
 
 void check_ready(crab_engine *e)
 {
@@ -1103,18 +1245,118 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         pidx = &pidx_u;
     }
 
+    // ---- partial updates (second half).  In a batch, a vector whose transition matrices differ from
+    // vector 0's on exactly one branch -- a finite-difference row that moves one branch length, or one branch's omega in
+    // the free-ratio model -- needs only the conditional likelihoods on the path from that branch to the root.  Vector
+    // 0's walk saves the tiles such paths start from and pass by; those vectors then run path programs in a second
+    // launch.  Same arithmetic in the same order as a whole walk: bit-identical results (tested). ----
+    const int G = pl.n_groups;
+    const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
+    const int Kg = pl.K / G, nn = e->n_nodes;
+    std::vector<int32_t> vec_node(G, -1);   // per vector: the one node whose branch differs from vector 0's, or -1: whole walk
+    int n_path = 0;
+    size_t save_bytes = 0;
+    if (G > 1 && prune_supports_paths() && !path_updates_disabled() && e->n_save_slots > 0) {
+        for (int b = 1; b < G; ++b) {
+            int node = -1, n_diff = 0;
+            for (int v = 0; v < nn && n_diff < 2; ++v) {
+                if (v == e->root || !e->reachable[v]) continue;
+                bool diff = false;
+                for (int k = 0; k < Kg && !diff; ++k) diff = (*pidx)[((size_t)b * Kg + k) * nn + v] != (*pidx)[(size_t)k * nn + v];
+                if (diff) ++n_diff, node = v;
+            }
+            if (n_diff == 1) vec_node[b] = node, ++n_path;
+        }
+        save_bytes = (size_t)e->n_save_slots * Kg * (size_t)n_tiles * 4 * SAVE_TILE_BYTES;
+        if (n_path < 4 || save_bytes > path_save_limit_bytes()) n_path = 0;
+        if (n_path > 0) {
+            try {
+                e->d_save.ensure(save_bytes);
+            } catch (const HipError &) {   // no room for the save area: whole walks for everybody
+                (void)hipGetLastError();
+                n_path = 0;
+            }
+        }
+        if (n_path == 0) std::fill(vec_node.begin(), vec_node.end(), -1);
+    }
+
     // ---- uploads ----
-    if (e->dev_ops.empty() || *pidx != e->dev_pidx) {   // the programs depend on the tree and on this table only
+    const size_t prog_stride = (size_t)dev_ops_padded((int64_t)e->ops.size());
+    if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node) {   // programs depend on the tree and these tables only
         std::vector<DevOp> progs;
-        resolve_programs(e, pl.K, *pidx, progs);
+        std::vector<ProgHdr> hdrs(pl.K);
+        if (n_path == 0) {
+            resolve_programs(e, pl.K, *pidx, progs);
+        } else {
+            DevOp filler{};
+            filler.w0 = OP_CONST;
+            progs.assign((size_t)pl.K * prog_stride, filler);
+            for (int b = 0; b < G; ++b) {
+                const PathProgram *pp = nullptr;
+                if (vec_node[b] >= 0) {
+                    auto it = e->path_programs.find(vec_node[b]);
+                    if (it == e->path_programs.end()) {
+                        it = e->path_programs.emplace(vec_node[b], PathProgram{}).first;
+                        build_path_program(e, vec_node[b], it->second);
+                    }
+                    pp = &it->second;
+                }
+                for (int k = 0; k < Kg; ++k) {
+                    const size_t c = (size_t)b * Kg + k;
+                    resolve_program(pp ? pp->ops : e->ops, pidx->data() + c * nn, b == 0, progs.data() + c * prog_stride);
+                }
+            }
+        }
+        ProgInfo whole;
+        whole.n_ops = (int)e->ops.size();
+        whole.first_gemm_op = e->first_gemm_op, whole.first_leaf_row = e->first_leaf_row, whole.first_leaf_op = e->first_leaf_op;
+        whole.second_leaf_row = e->second_leaf_row, whole.third_leaf_row = e->third_leaf_row;
+        for (int b = 0; b < G; ++b) {
+            const ProgInfo &pi_ = vec_node[b] >= 0 ? e->path_programs[vec_node[b]].info : whole;
+            for (int k = 0; k < Kg; ++k) {
+                ProgHdr &h = hdrs[(size_t)b * Kg + k];
+                h.n_ops = pi_.n_ops, h.first_gemm_op = pi_.first_gemm_op, h.first_leaf_row = pi_.first_leaf_row;
+                h.first_leaf_op = pi_.first_leaf_op, h.second_leaf_row = pi_.second_leaf_row, h.third_leaf_row = pi_.third_leaf_row;
+                h.save_cls = k;
+                h.pad = 0;
+            }
+        }
+        // launch lists: whole walks first; path programs in a second launch, dealt into eight groups of similar total
+        // length (one per XCD chunk of the kernel's work-item order)
+        std::vector<int32_t> lists;
+        for (int b = 0; b < G; ++b)
+            if (vec_node[b] < 0)
+                for (int k = 0; k < Kg; ++k) lists.push_back(b * Kg + k);
+        const int n_whole = (int)lists.size();
+        if (n_path > 0) {
+            std::vector<int> order;
+            for (int b = 0; b < G; ++b)
+                if (vec_node[b] >= 0) order.push_back(b);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hdrs[(size_t)x * Kg].n_ops > hdrs[(size_t)y * Kg].n_ops; });
+            for (int g8 = 0; g8 < 8; ++g8)
+                for (size_t i = g8; i < order.size(); i += 8)
+                    for (int k = 0; k < Kg; ++k) lists.push_back(order[i] * Kg + k);
+        }
         e->dev_pidx = *pidx;
-        {
-            e->d_ops.ensure(progs.size());
-            HIP_CHECK(hipMemcpyAsync(e->d_ops.p, progs.data(), progs.size() * sizeof(DevOp), hipMemcpyHostToDevice, e->stream));
-            HIP_CHECK(hipStreamSynchronize(e->stream));  // progs is pageable
-            e->dev_ops.swap(progs);
+        e->dev_vec_node = vec_node;
+        e->dev_n_whole = n_whole;
+        e->d_ops.ensure(progs.size());
+        e->d_hdr.ensure(hdrs.size());
+        e->d_cls.ensure(lists.size() + 1);
+        HIP_CHECK(hipMemcpyAsync(e->d_ops.p, progs.data(), progs.size() * sizeof(DevOp), hipMemcpyHostToDevice, e->stream));
+        HIP_CHECK(hipMemcpyAsync(e->d_hdr.p, hdrs.data(), hdrs.size() * sizeof(ProgHdr), hipMemcpyHostToDevice, e->stream));
+        HIP_CHECK(hipMemcpyAsync(e->d_cls.p, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));  // the sources are pageable
+        e->dev_ops.swap(progs);
+        // products and gathers this table executes (per pattern)
+        e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
+        for (int b = 0; b < G; ++b) {
+            const ProgInfo &pi_ = vec_node[b] >= 0 ? e->path_programs[vec_node[b]].info : ProgInfo{};
+            e->dev_gemm_per_pat += (int64_t)Kg * (vec_node[b] >= 0 ? pi_.n_gemm : e->n_gemm_edges);
+            e->dev_leaf_per_pat += (int64_t)Kg * (vec_node[b] >= 0 ? pi_.n_leaf : e->n_leaf_edges);
         }
     }
+    const int n_whole = e->dev_n_whole, n_path_cls = pl.K - n_whole;
     // the small per-call inputs travel in one copy: [t_eff M][pi NS][props K][eigensystem slot per matrix, int32 M]
     const size_t n_small = (size_t)M + NS + pl.K + ((size_t)M + 1) / 2;
     e->h_small.ensure(n_small);
@@ -1130,13 +1372,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     double *d_teff = e->d_small.p, *d_pi = d_teff + M, *d_props = d_pi + NS;
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
     e->d_P.ensure((size_t)M * P_ELEMS);
-    const int64_t n_tiles = e->n_pat_pad / prune_tile_width();
-    const int grid = prune_grid_size(n_tiles * pl.K, e->device);
-    e->d_stack.ensure(prune_stack_doubles(grid, e->max_depth));
-    e->d_stack_e.ensure(prune_stack_ints(grid, e->max_depth));
+    const int grid = prune_grid_size(n_tiles * n_whole, e->device);
+    const int grid_path = n_path_cls > 0 ? prune_grid_size(n_tiles * n_path_cls, e->device) : 0;
+    e->d_stack.ensure(prune_stack_doubles(std::max(grid, grid_path), e->max_depth));
+    e->d_stack_e.ensure(prune_stack_ints(std::max(grid, grid_path), e->max_depth));
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
-    const int G = pl.n_groups;
     e->d_patlnl.ensure((size_t)G * e->n_pat_pad);
     e->d_partials.ensure((size_t)G * std::max(1, mix_blocks(e->n_pat)));
     e->d_lnL.ensure(G);
@@ -1153,7 +1394,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.n_ops = (int32_t)e->ops.size();
     pa.n_ops_pad = (int32_t)dev_ops_padded((int64_t)e->ops.size());
     pa.P = e->d_P.p;
-    pa.K = pl.K;
+    pa.K = n_whole;
+    pa.hdr = n_path_cls > 0 ? e->d_hdr.p : nullptr;
+    pa.cls_list = n_path_cls > 0 ? e->d_cls.p : nullptr;
+    pa.save = n_path_cls > 0 ? (char *)e->d_save.p : nullptr;
+    pa.save_K = Kg;
     pa.codes = e->d_codes.p;
     pa.n_pat_pad = e->n_pat_pad;
     pa.pi_pad = d_pi;
@@ -1170,6 +1415,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.third_leaf_row = e->third_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
+    if (n_path_cls > 0) {   // the path programs read what vector 0's walk saved: same stream, after it
+        pa.K = n_path_cls;
+        pa.cls_list = e->d_cls.p + n_whole;
+        launch_prune(pa, grid_path, e->stream);
+    }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
     e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0) +
@@ -1290,8 +1540,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_pidx = *pidx;
     e->last_K = pl.K;
     e->last_M = M;
-    e->last_dense = e->n_gemm_edges * e->n_pat * pl.K;
-    e->last_gather = e->n_leaf_edges * e->n_pat * pl.K;
+    e->last_dense = e->dev_gemm_per_pat * e->n_pat;     // products and gathers actually executed
+    e->last_gather = e->dev_leaf_per_pat * e->n_pat;
+    e->last_n_path = n_path_cls / std::max(1, Kg);
 
     if (pl.post_weights) {
         const double *src = e->h_out.p + G;
@@ -1556,6 +1807,7 @@ int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const in
     return guarded(e, [&] {
         e->have_tree = false;
         e->dev_ops.clear();
+        e->path_programs.clear();
         build_tree(e, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
         e->have_tree = true;
     });
@@ -1898,6 +2150,13 @@ int crab_eig_pool_stats(const crab_engine *e, int64_t *hits, int64_t *misses, in
     return CRAB_OK;
 }
 
+int crab_last_partial_updates(const crab_engine *e, int *n_vectors)
+{
+    if (!e || !n_vectors) return CRAB_ERR_ARG;
+    *n_vectors = e->is_multi() ? e->shards[0]->last_n_path : e->last_n_path;
+    return CRAB_OK;
+}
+
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)
 {
     if (!e) return CRAB_ERR_ARG;
@@ -1928,6 +2187,32 @@ int crab_compile_tree(int n_nodes, const int32_t *node_ids, const int32_t *paren
                 const TreeOp &o = tp.ops[i];
                 int32_t *r = ops_out + 5 * i;
                 r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot;
+            }
+        }
+    });
+}
+
+int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
+                              int n_leaves, int node, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_save_slots)
+{
+    return guarded(nullptr, [&] {
+        TreeProgram tp;
+        build_tree(&tp, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        const std::vector<TreeOp> *ops = &tp.ops;
+        PathProgram pp;
+        if (node >= 0) {
+            if (node >= n_nodes || node == tp.root || !tp.reachable[node]) fail(CRAB_ERR_ARG, "crab_compile_path_program: no branch above this node");
+            build_path_program(&tp, node, pp);
+            ops = &pp.ops;
+        }
+        if (n_ops) *n_ops = (int)ops->size();
+        if (n_save_slots) *n_save_slots = tp.n_save_slots;
+        if (ops_out) {
+            if ((int)ops->size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
+            for (size_t i = 0; i < ops->size(); ++i) {
+                const TreeOp &o = (*ops)[i];
+                int32_t *r = ops_out + 6 * i;
+                r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot; r[5] = o.sv;
             }
         }
     });

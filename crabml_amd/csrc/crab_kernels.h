@@ -40,7 +40,10 @@ __host__ __device__ inline int p_gather_index(int i, int j) { return P_IMAGE + j
 // product consumes the child's tile straight from registers, register idx being k-step idx.
 
 // ---- tree program ---------------------------------------------------------------------------
-enum : int32_t { OP_GEMM = 0, OP_LEAF = 1, OP_CONST = 2 };
+enum : int32_t {
+    OP_GEMM = 0, OP_LEAF = 1, OP_CONST = 2,
+    OP_LOAD = 3   // path programs: the current tile is (or, with F_MUL_PROD, is multiplied by) save slot `sv` of the base pass
+};
 enum : int32_t {
     F_MUL_PROD = 1,   // multiply the new term into the running product of this node
     F_POP_MUL = 2,    // multiply the new term with stack[slot] (the product saved before a sibling subtree)
@@ -53,8 +56,13 @@ enum : int32_t {
     F_PRE_LATE = 64,  // any op: at its end, request the columns of leaf edge pre_node (the next op is that leaf edge)
     F_PRE_DYING = 128,  // GEMM: also request the columns of leaf edge pre_node_b into the registers of the product's B
                         // operand as they die, k-tile by k-tile; they are then in the landing tile of the ops that follow
-    F_IN_LANDING = 256  // LEAF (with F_MUL_PROD): the columns were requested by the preceding product's F_PRE_DYING
+    F_IN_LANDING = 256, // LEAF (with F_MUL_PROD): the columns were requested by the preceding product's F_PRE_DYING
+    // partial updates (a finite-difference stencil row that moves one branch re-walks only the path from that branch to
+    // the root, on tiles the base vector's walk left in HBM): see "save area" below
+    F_POP_SAVED = 512,  // GEMM with F_POP_MUL (path programs): the saved product is save slot `slot`, not stack slot `slot`
+    F_SAVE = 1024       // GEMM (base vector's program): store this edge's tiles in save slots sv, sv+1, sv+2
 };
+constexpr int OP_FLAG_BITS = 12;   // DevOp::w0 = kind | flags << 2 | slot << (2 + OP_FLAG_BITS)
 // The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
 // device form (DevOp, matrix indices) before upload, so the kernel never chases the (class, node) -> matrix table.
 struct TreeOp {
@@ -67,9 +75,10 @@ struct TreeOp {
     int32_t pre_node_b;  // F_PRE_DYING: child node of the second leaf edge requested by this op
     int32_t pre_row2;    // alignment rows whose codes refill the two-deep code queue after the request(s), -1 none:
     int32_t pre_row3;    //   the leaf edges two (and, with F_PRE_DYING, three) after the first one requested here
+    int32_t sv;          // GEMM: first of this edge's three save slots; OP_LOAD: the save slot to read
 };
 struct alignas(16) DevOp {
-    int32_t w0;        // kind | flags << 2 | slot << 11
+    int32_t w0;        // kind | flags << 2 | slot << 14
     int32_t mat;       // matrix index of this edge in PruneArgs::P
     int32_t arg;       // LEAF: alignment row of the NEXT leaf edge (-1 none); GEMM: matrix of the next GEMM op (-1 none);
                        // CONST: 1 -> ones, 0 -> zeros
@@ -77,8 +86,21 @@ struct alignas(16) DevOp {
     int32_t pre_row2;  // code-queue refill rows (see TreeOp)
     int32_t pre_mat_b; // F_PRE_DYING: matrix of the second leaf edge
     int32_t pre_row3;
+    int32_t sv;        // save slot (see TreeOp)
+};
+// Per-program header: programs of one launch may differ in length (path programs are a few ops long).
+struct alignas(16) ProgHdr {
+    int32_t n_ops;
+    int32_t first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row;   // as in PruneArgs
+    int32_t save_cls;  // class index inside the save area (the base vector's class with the same rate matrices)
     int32_t pad;
 };
+// Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
+// of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);
+// slot sv+2 = the edge's message P_c L_c before it is multiplied into the running product (if the op has F_POP_MUL).
+// A tile is stored like a stack slot (8 KiB per wave) followed by its 64 per-lane exponents; slot s of class k,
+// pattern tile t, wave w lives at ((s * save_K + k) * n_tiles + t) * 4 + w tiles of SAVE_TILE_BYTES.
+constexpr size_t SAVE_TILE_BYTES = 16 * 64 * 8 + 64 * 4;
 // Device programs are padded to a multiple of 64 ops plus one extra batch (the kernel reads one batch ahead).
 inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 + 64; }
 
@@ -105,6 +127,10 @@ struct PruneArgs {
     int32_t max_depth;
     double *out_f;            // [K][n_pat_pad]  scaled site likelihood per class
     int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
+    const ProgHdr *hdr;       // [number of programs] per-program headers, or nullptr: n_ops and the five fields below apply to all
+    const int32_t *cls_list;  // programs (= rows of out_f) this launch walks, or nullptr: 0 .. K-1
+    char *save;               // save area, or nullptr
+    int32_t save_K;           // classes in the save area
     int32_t first_gemm_op;    // index of the first GEMM op (-1 if none)
     int32_t first_leaf_row;   // alignment row of the first leaf edge in program order (-1 if none)
     int32_t first_leaf_op;    // index of that op if it is op 0 (its columns are requested before the walk starts), else -1
@@ -115,6 +141,8 @@ struct PruneArgs {
 // tile of a product that pops a deeper, global-memory slot), and whether it has a prefetch tile at all.
 int prune_reg_stack_slots();
 bool prune_has_prefetch();
+// Whether the configured kernel executes OP_LOAD / F_SAVE / F_POP_SAVED (the 64-pattern kernel does).
+bool prune_supports_paths();
 // Patterns per workgroup for the configuration launch_prune will use.
 int prune_tile_width();
 // Number of workgroups launch_prune will use for n_work = tiles*K work items on HIP device `device` (persistent grid).

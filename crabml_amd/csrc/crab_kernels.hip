@@ -480,6 +480,9 @@ struct Walk {
     unsigned lds_a;            // LDS byte address of this lane's A operand inside a tile pair
     char *smem;
     int wave, lane;
+    int n_ops;                 // length of this program
+    char *save0;               // this wave's tile of save slot 0 (uniform), or nullptr; slot s is s * save_stride further
+    size_t save_stride;
 #ifdef CRAB_PROF
     unsigned long long prof_acc[12], prof_last;
 #endif
@@ -609,6 +612,25 @@ __device__ __forceinline__ void pop_mul(Walk<NT> &w, int slot, int (&eY)[NT])
     for (int nt = 0; nt < NT; ++nt) eY[nt] += es[nt];
 }
 
+// Save area of the base vector's walk (crab_kernels.h): tile X and its exponents into / out of save slot `slot`.
+template <int NT, int X>
+__device__ __forceinline__ void save_tile(Walk<NT> &w, int slot, const int (&eX)[NT])
+{
+    static_assert(NT == 1, "path programs are built for the 64-pattern kernel only");
+    char *dst = w.save0 + (size_t)slot * w.save_stride;
+    ((int32_t *)(dst + 16 * 64 * 8))[w.lane] = eX[0];
+    t_store<NT, X>(dst, w.stack_voff);
+}
+template <int NT, int D>
+__device__ __forceinline__ void load_saved(Walk<NT> &w, int slot, int (&es)[NT])
+{
+    static_assert(NT == 1, "path programs are built for the 64-pattern kernel only");
+    const char *src = w.save0 + (size_t)slot * w.save_stride;
+    es[0] = ((const int32_t *)(src + 16 * 64 * 8))[w.lane];
+    t_load<NT, D>(src, w.stack_voff);
+    r_wait_vm0();
+}
+
 // Runs the program on the current tile X (exponents eX) until a product Y = P X has been executed (returns false:
 // Y is the current tile now and X is free) or the program ends (returns true: X is the root's tile).
 // The other tile Y is dead on entry and serves as landing zone for columns and saved products.  Every update of
@@ -620,12 +642,14 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
     constexpr int G = Plan<NT>::G;
     const PruneArgs &a = w.a;
 
-    while (w.ip < a.n_ops) {
+    while (w.ip < w.n_ops) {
         PROF_T(9)
         const int il = w.ip & 63;
         if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
         const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
-        const int kind = w0 & 3, flags = (w0 >> 2) & 511, slot = w0 >> 11;
+        const int kind = w0 & 3, flags = (w0 >> 2) & ((1 << OP_FLAG_BITS) - 1), slot = w0 >> (2 + OP_FLAG_BITS);
+        int sv = 0;
+        if constexpr (NT == 1) sv = __builtin_amdgcn_readlane(w.batch.sv, il);
         const int mat = __builtin_amdgcn_readlane(w.batch.mat, il);
         const int arg = __builtin_amdgcn_readlane(w.batch.arg, il);
         int pre_mat = -1, pre_row2 = -1, pre_mat_b = -1, pre_row3 = -1;
@@ -645,6 +669,8 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             PROF_T(1)
             __syncthreads();
             PROF_T(2)
+            if constexpr (NT == 1)
+                if (flags & F_SAVE) save_tile<NT, X>(w, sv, eX);   // the operand of this edge's product
             Ride<(PRE ? G : -1), X> ride;
             ride.dma_src = arg >= 0 ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
             ride.dma_dst = w.smem + (w.buf ^ 1) * 32768 + w.wave * 8192;
@@ -666,10 +692,24 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             w.buf ^= 1;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) eY[nt] = eX[nt];
-            if (flags & F_POP_MUL) pop_mul<NT, Y, X>(w, slot, eY);
+            if constexpr (NT == 1) {
+                if ((flags & (F_SAVE | F_POP_MUL)) == (F_SAVE | F_POP_MUL)) save_tile<NT, Y>(w, sv + 2, eY);   // the edge's message
+                if (flags & F_POP_SAVED) {                     // path program: the running product the base walk saved
+                    int es[NT];
+                    load_saved<NT, X>(w, slot, es);
+                    t_mul<NT, Y, X>();
+                    eY[0] += es[0];
+                } else if (flags & F_POP_MUL) {
+                    pop_mul<NT, Y, X>(w, slot, eY);
+                }
+            } else {
+                if (flags & F_POP_MUL) pop_mul<NT, Y, X>(w, slot, eY);
+            }
             PROF_T(4)
             if (flags & F_RESCALE) t_normalise<NT, Y>(eY);
             PROF_T(7)
+            if constexpr (NT == 1)
+                if ((flags & (F_SAVE | F_FIN)) == F_SAVE) save_tile<NT, Y>(w, sv + 1, eY);   // the parent's running product
             if (flags & F_PUSH) push<NT, Y>(w, slot, eY);
             PROF_T(8)
             return false;
@@ -708,6 +748,18 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
                 PROF_T(5)
                 if (flags & F_MUL_PROD) t_mul<NT, X, Y>();
                 PROF_T(6)
+            }
+        } else if (kind == OP_LOAD) {   // path program: a tile the base vector's walk saved
+            if constexpr (NT == 1) {
+                int es[NT];
+                if (flags & F_MUL_PROD) {
+                    load_saved<NT, Y>(w, sv, es);
+                    t_mul<NT, X, Y>();
+                    eX[0] += es[0];
+                } else {
+                    load_saved<NT, X>(w, sv, es);
+                    eX[0] = es[0];
+                }
             }
         } else {  // OP_CONST: childless non-leaf node
             t_const_seq<X>(arg, w.lane >> 4, a.n_states, std::make_integer_sequence<int, 16>{});
@@ -765,7 +817,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const long long n_work = n_tiles * a.K;
+    const long long n_work = n_tiles * a.K;   // a.K programs are walked by this launch
     constexpr size_t slot_bytes = (size_t)NT * 16 * 64 * 8;
 
     // Work items are ordered class-major and cut into one contiguous chunk per XCD (workgroups are dealt round-robin
@@ -780,8 +832,16 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = n_work * xcd / N_XCD, chunk_hi = n_work * (xcd + 1) / N_XCD;
     for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
-        const int cls = (int)(wi / n_tiles);
-        const long long tile = wi - (long long)cls * n_tiles;
+        const int ci = (int)(wi / n_tiles);
+        const long long tile = wi - (long long)ci * n_tiles;
+        const int cls = a.cls_list ? a.cls_list[ci] : ci;
+        int n_ops = a.n_ops, first_gemm_op = a.first_gemm_op, first_leaf_row = a.first_leaf_row, first_leaf_op = a.first_leaf_op,
+            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls;
+        if (a.hdr) {
+            const ProgHdr h = a.hdr[cls];
+            n_ops = h.n_ops, first_gemm_op = h.first_gemm_op, first_leaf_row = h.first_leaf_row, first_leaf_op = h.first_leaf_op;
+            second_leaf_row = h.second_leaf_row, third_leaf_row = h.third_leaf_row, save_cls = h.save_cls;
+        }
         const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
 
         Walk<NT> w{a};
@@ -797,6 +857,9 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.smem = smem;
         w.wave = wave;
         w.lane = lane;
+        w.n_ops = n_ops;
+        w.save_stride = (size_t)a.save_K * (size_t)n_tiles * 4 * SAVE_TILE_BYTES;
+        w.save0 = a.save ? a.save + (((size_t)save_cls * (size_t)n_tiles + (size_t)tile) * 4 + wave) * SAVE_TILE_BYTES : nullptr;
 
 #ifdef CRAB_PROF
         for (int i = 0; i < 12; ++i) w.prof_acc[i] = prof_keep[i];
@@ -811,15 +874,15 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 
         __syncthreads();  // every wave is done reading LDS for the previous work item
         __builtin_amdgcn_s_setprio(1);
-        if (a.first_gemm_op >= 0) dma_matrix(a.P + (size_t)w.ops[a.first_gemm_op].mat * P_ELEMS, smem, wave, lane);
+        if (first_gemm_op >= 0) dma_matrix(a.P + (size_t)w.ops[first_gemm_op].mat * P_ELEMS, smem, wave, lane);
         // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
         w.batch = w.ops[lane];
-        if (a.first_leaf_row >= 0) load_code_offsets<NT>(w, a.first_leaf_row, w.code_off);
+        if (first_leaf_row >= 0) load_code_offsets<NT>(w, first_leaf_row, w.code_off);
         if constexpr (Plan<NT>::HAS_PRE) {
-            if (a.second_leaf_row >= 0) load_code_offsets<NT>(w, a.second_leaf_row, w.code_off2);
-            if (a.first_leaf_op >= 0) {
-                issue_columns<NT, Plan<NT>::G>(w, w.ops[a.first_leaf_op].mat);
-                refill_codes1<NT>(w, a.third_leaf_row);
+            if (second_leaf_row >= 0) load_code_offsets<NT>(w, second_leaf_row, w.code_off2);
+            if (first_leaf_op >= 0) {
+                issue_columns<NT, Plan<NT>::G>(w, w.ops[first_leaf_op].mat);
+                refill_codes1<NT>(w, third_leaf_row);
             }
         }
 
@@ -904,6 +967,7 @@ static int blocks_per_cu()
 int prune_tile_width() { return 64 * chosen_nt(); }
 int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }
 bool prune_has_prefetch() { return chosen_nt() == 1 ? Plan<1>::HAS_PRE : Plan<2>::HAS_PRE; }
+bool prune_supports_paths() { return chosen_nt() == 1; }
 
 int prune_grid_size(int64_t n_work, int device)
 {
@@ -920,7 +984,7 @@ size_t prune_stack_ints(int grid, int max_depth) { return (size_t)grid * 4 * (ma
 
 void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
 {
-    if (grid <= 0 || a.n_ops <= 0) return;
+    if (grid <= 0 || (a.n_ops <= 0 && !a.hdr)) return;
     const int nt = chosen_nt();
     const long long n_tiles = a.n_pat_pad / (64 * nt);
     const size_t lds = prune_lds_bytes();

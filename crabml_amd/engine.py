@@ -320,6 +320,12 @@ class Engine:
         self._check(self._lib.crab_eig_pool_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def last_partial_updates(self) -> int:
+        """Vectors of the last batched evaluation that re-walked only a branch-to-root path (crab_last_partial_updates)."""
+        n = C.c_int()
+        self._check(self._lib.crab_last_partial_updates(self._h, C.byref(n)))
+        return n.value
+
     def last_work(self):
         """(dense MFMA updates, gathered leaf updates) of the last evaluation, in pattern x branch x class units."""
         a, b = C.c_int64(), C.c_int64()
@@ -347,6 +353,23 @@ def compile_tree(parents, leaf_node_ids, node_ids=None):
     L.check(lib.crab_compile_tree(len(par), idp, parp, leafp, len(leaf), ops.ctypes.data_as(L.ip), n_ops.value,
                                   C.byref(n_ops), C.byref(depth)))
     return ops, depth.value
+
+
+def compile_path_program(parents, leaf_node_ids, node=-1, node_ids=None):
+    """int32 [n_ops, 6] (kind, node, flags, arg, slot, save slot): the program that recomputes the root when only the
+    branch above ``node`` moved (node = -1: the whole-tree program in the same form), and the number of save slots."""
+    lib = L.load()
+    par, parp = L.i32(parents)
+    leaf, leafp = L.i32(leaf_node_ids)
+    idp = None
+    if node_ids is not None:
+        ids, idp = L.i32(node_ids)
+    n_ops, n_slots = C.c_int(), C.c_int()
+    L.check(lib.crab_compile_path_program(len(par), idp, parp, leafp, len(leaf), int(node), None, 0, C.byref(n_ops), C.byref(n_slots)))
+    ops = np.zeros((n_ops.value, 6), dtype=np.int32)
+    L.check(lib.crab_compile_path_program(len(par), idp, parp, leafp, len(leaf), int(node), ops.ctypes.data_as(L.ip), n_ops.value,
+                                          C.byref(n_ops), C.byref(n_slots)))
+    return ops, n_slots.value
 
 
 def compress_patterns(codes, n_states=61):

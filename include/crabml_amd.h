@@ -192,9 +192,20 @@ int crab_model_a_quantities(double kappa, double omega0, double omega2, double p
 /* Timing of the last crab_eval_* on this engine, in milliseconds (HIP events on the engine's
  * stream): whole device section, and the pruning kernel alone.  For bench.py's roofline block. */
 int crab_last_timing(const crab_engine *e, double *device_ms, double *prune_kernel_ms, double *host_eigen_ms);
-/* Static facts about the pruning launch of the last evaluation: number of dense
- * (pattern x branch x class) updates executed as MFMA products, and of leaf-edge updates done as gathers. */
+/* Static facts about the pruning launches of the last evaluation: number of dense
+ * (pattern x branch x class) updates executed as MFMA products, and of leaf-edge updates done as gathers
+ * (with partial updates: those actually executed, not those a whole walk of every vector would take). */
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates);
+
+/* Partial updates (second half).  In every batched call (B > 1) a vector whose transition matrices differ
+ * from vector 0's on exactly ONE branch -- a finite-difference row that moves one branch length, or one branch's omega
+ * under the free-ratio model -- is evaluated by re-walking only the path from that branch to the root, on conditional
+ * likelihoods that vector 0's walk left in HBM (three 8 KiB tiles per internal edge, wave and class; used when at
+ * least 4 vectors qualify and the area fits CRAB_PATH_SAVE_GB, default 96).  Same products in the same order as a
+ * whole walk: results are bit-identical (tested); CRAB_NO_PATH_UPDATES=1 switches it off.  Put the centre of a stencil
+ * first.  This call reports how many vectors of the last evaluation took the short path.  Replaces the n_params + 1
+ * whole-tree evaluations per gradient of optimize/optimizer.py:1197-1203. */
+int crab_last_partial_updates(const crab_engine *e, int *n_vectors);
 
 /* Eigensystem pool of this engine since creation: distinct decompositions found resident (hits), decomposed anew
  * (misses), and entries resident now.  Replaces nothing in the reference (it decomposes every matrix on every call,
@@ -231,6 +242,11 @@ int crab_build_codon_q_matrix(double kappa, double omega, const double *pi, int 
  * pass ops_out = NULL to query n_ops first. */
 int crab_compile_tree(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
                       int n_leaves, int32_t *ops_out, int ops_capacity, int *n_ops, int *max_depth);
+/* The program of a partial update (crab_last_partial_updates): what is recomputed when only the branch above `node`
+ * moves, 6 int32 per op {kind, node, flags, arg, slot, save slot}; node = -1 gives the whole-tree program in the same
+ * 6-field form.  n_save_slots: tiles per (class, pattern tile, wave) the base walk saves. */
+int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
+                              int n_leaves, int node, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_save_slots);
 /* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
 int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
                            int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,

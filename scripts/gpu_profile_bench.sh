@@ -7,8 +7,8 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$name.log 2>&1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-target > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+run() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-target > $OUT/$name.log 2>&1; }
 run l2 TCC_HIT_sum TCC_MISS_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE

@@ -431,3 +431,51 @@ def test_shim_checks_the_number_of_leaf_node_ids():
     ts = tree_structure(c["parent"])
     with pytest.raises(ValueError, match="leaf_node_ids has 6 entries but sequences has 7 rows"):
         shim.compute_log_likelihood(c["Q"][0], c["pi"], ts, c["branch_lengths"].tolist(), [], c["sequences"], list(range(6)))
+
+
+def test_path_programs_recompute_exactly_what_a_moved_branch_changes():
+    """Partial updates: for every branch of random trees (polytomies, unary nodes, leaves on the root included), the
+    path program run on the tiles a base walk saved must give what the whole-tree program gives when that branch's
+    transition matrix is replaced -- the same products in the same order, hence the same bits."""
+    from crabml_amd.engine import compile_path_program
+    rng = np.random.default_rng(7)
+    n = 7
+    for trial in range(12):
+        n_leaves = int(rng.integers(2, 14))
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1 or nxt == n_leaves:
+            k = int(min(len(open_nodes), rng.choice([1, 2, 2, 2, 3, 4])))
+            if len(open_nodes) == 1 and nxt > n_leaves and k == 1:
+                break
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        n_nodes = nxt
+        par = np.array([parent.get(v, -1) for v in range(n_nodes)], dtype=np.int32)
+        leaf = np.arange(n_leaves, dtype=np.int32)
+        S = 9
+        codes = rng.integers(0, n, size=(n_leaves, S)).astype(np.int32)
+        codes[rng.random(codes.shape) < 0.1] = n
+        pi = rng.dirichlet(np.ones(n))
+        P = {v: rng.dirichlet(np.ones(n), size=n) for v in range(n_nodes)}
+        whole, n_slots = compile_path_program(par, leaf)
+        saved = {}
+        base = emulate_program(whole, P, codes, pi, n_states=n, saved=saved, save=True)
+        assert np.array_equal(base, emulate_program(whole, P, codes, pi, n_states=n))
+        n_gemm = int((whole[:, 0] == 0).sum())
+        assert n_slots == 3 * n_gemm
+        for v in range(n_nodes):
+            if par[v] < 0:
+                continue
+            path, _ = compile_path_program(par, leaf, node=v)
+            P2 = dict(P)
+            P2[v] = rng.dirichlet(np.ones(n), size=n)
+            want = emulate_program(whole, P2, codes, pi, n_states=n)
+            got = emulate_program(path, P2, codes, pi, n_states=n, saved=saved)
+            assert np.array_equal(got, want), f"trial {trial}, node {v}"
+            assert len(path) <= len(whole) + 1
+            assert not (path[:, 2] & 4).any()                       # no stack traffic on a path
+    with pytest.raises(ValueError, match="no branch above"):
+        compile_path_program([2, 2, -1], [0, 1], node=2)

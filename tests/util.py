@@ -54,34 +54,55 @@ OP_GEMM, OP_LEAF, OP_CONST = 0, 1, 2
 F_MUL_PROD, F_POP_MUL, F_PUSH, F_FIN, F_RESCALE = 1, 2, 4, 8, 16
 
 
-def emulate_program(ops, P_of_node, codes, pi, n_states=61):
+OP_LOAD = 3
+F_POP_SAVED, F_SAVE = 512, 1024
+
+
+def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=False):
     """Run the op list exactly as prune_kernel does (minus rescaling, which is exact) and return f[s].
 
-    P_of_node[v] is the n x n transition matrix on the branch above node v; codes [n_rows, S]."""
+    P_of_node[v] is the n x n transition matrix on the branch above node v; codes [n_rows, S].  Ops have 5 fields
+    (crab_compile_tree) or 6 (crab_compile_path_program: the sixth is the save slot).  ``save=True`` fills the dict
+    ``saved`` the way a base walk with F_SAVE fills the save area (slot sv: operand of each product, sv+1: the parent's
+    running product after the op unless it completes the parent, sv+2: the message before a pop); path programs (OP_LOAD,
+    F_POP_SAVED) read it."""
     S = codes.shape[1]
     cur = prod = None
     stack = {}
-    for kind, node, flags, arg, slot in ops:
+    for op in ops:
+        kind, node, flags, arg, slot = (int(x) for x in op[:5])
+        sv = int(op[5]) if len(op) > 5 else 0
         if kind == OP_GEMM:
-            t = cur @ P_of_node[node].T
+            if save:
+                saved[sv] = prod
+            t = prod @ P_of_node[node].T          # the current tile: a product always follows its operand's last op
+            if save and flags & F_POP_MUL:
+                saved[sv + 2] = t
         elif kind == OP_LEAF:
             c = codes[arg]
             valid = (c >= 0) & (c < n_states)
             t = np.where(valid[:, None], P_of_node[node].T[np.where(valid, c, 0)], P_of_node[node].sum(axis=1)[None, :])
+        elif kind == OP_LOAD:
+            t = saved[sv]
         else:
             t = np.full((S, n_states), float(arg))
         if flags & F_MUL_PROD:
             t = t * prod
-        if flags & F_POP_MUL:
+        if flags & F_POP_SAVED:
+            t = t * saved[slot]
+        elif flags & F_POP_MUL:
             t = t * stack.pop(slot)
         prod = t
+        if save and kind == OP_GEMM and not flags & F_FIN:
+            saved[sv + 1] = prod
         if flags & F_PUSH:
             assert slot not in stack, "stack slot overwritten while live"
             stack[slot] = prod
         if flags & F_FIN:
             cur = prod
     assert not stack, "stack not empty at the end of the program"
-    return cur @ pi
+    assert cur is prod, "the last op must complete the root"
+    return prod @ pi
 
 
 # -----------------------------------------------------------------------------------------------
