@@ -134,7 +134,7 @@ def _class_parameters(model_class, mle_params, names, x, pi):
     return float(model.kappa), np.asarray(omegas, dtype=np.float64), np.asarray(props, dtype=np.float64)
 
 
-def negative_log_likelihoods(engine, model_class, mle_params, names, points, pi, branch_lengths):
+def negative_log_likelihoods(engine, model_class, mle_params, names, points, pi, branch_lengths, no_clamp=False):
     """``neg_log_likelihood`` of beb.py:247-263 at many parameter vectors in ONE call through the C ABI
     (crab_eval_codon_site_classes with B = number of in-bounds points); out-of-bounds points are +inf as there."""
     out = np.full(len(points), np.inf)
@@ -143,7 +143,8 @@ def negative_log_likelihoods(engine, model_class, mle_params, names, points, pi,
         cls = [_class_parameters(model_class, mle_params, names, points[i], pi) for i in ok]
         out[ok] = -engine.codon_site_classes(np.array([c[0] for c in cls]), np.array([c[1] for c in cls]),
                                              np.array([c[2] for c in cls]), pi,
-                                             np.broadcast_to(np.asarray(branch_lengths, dtype=np.float64), (len(ok), len(branch_lengths))))
+                                             np.broadcast_to(np.asarray(branch_lengths, dtype=np.float64), (len(ok), len(branch_lengths))),
+                                             no_clamp=no_clamp)
     return out
 
 

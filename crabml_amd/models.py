@@ -184,13 +184,24 @@ def _beta_quantiles(p_beta, q_beta, K):
     return tuple(_median_quantiles(lambda p: beta.ppf(p, p_beta, q_beta), K))
 
 
+@functools.lru_cache(maxsize=256)
+def _beta_quantiles_c(p_beta, q_beta, K):
+    """The same quantiles from the C library (crab_discretise_omega: within 2e-11 relative of scipy over the optimisers'
+    range, tests/test_host_logic.py; 5 us per quantile against 120 us for scipy.stats.beta.ppf, which at gene scale was
+    most of the host time of a fit).  Used by the optimiser mirrors; fixtures and generators stay on scipy."""
+    from .engine import discretise_omega
+    return tuple(float(x) for x in discretise_omega("beta", p_beta, q_beta, K))
+
+
 class M7CodonModel(_SiteClassModel):
+    c_quantiles = False    # instances made by the optimiser mirrors set this
+
     def __init__(self, kappa=2.0, p_beta=0.5, q_beta=0.5, ncatG=10, pi=None):
         self.kappa, self.p_beta, self.q_beta, self.ncatG = kappa, max(p_beta, 0.005), max(q_beta, 0.005), ncatG
         self.pi = _normalise_pi(pi)
 
     def _beta_omegas(self):
-        return list(_beta_quantiles(self.p_beta, self.q_beta, self.ncatG))
+        return list((_beta_quantiles_c if self.c_quantiles else _beta_quantiles)(self.p_beta, self.q_beta, self.ncatG))
 
     def get_site_classes(self):
         K = self.ncatG

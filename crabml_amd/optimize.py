@@ -23,6 +23,12 @@ from .likelihood_rust import RustLikelihoodCalculator
 EPS = 1e-8   # scipy's L-BFGS-B default ``eps``, the absolute step of its numerical gradient
 
 
+def _bound_arrays(bounds):
+    lb = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
+    ub = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+    return lb, ub
+
+
 def forward_difference_points(x, bounds=None, eps: float = EPS):
     """(points [n, n], dx [n]): row i is x with x_i + h_i, where h follows scipy's rules for an absolute step with
     bounds -- +eps, flipped to -eps where x_i + eps leaves [lb_i, ub_i] and eps still fits on the other side, else the
@@ -33,8 +39,7 @@ def forward_difference_points(x, bounds=None, eps: float = EPS):
     lost = (x + h) - x == 0                                   # a step lost to rounding falls back to a relative one
     h[lost] = np.sqrt(np.finfo(np.float64).eps) * np.where(x[lost] >= 0, 1.0, -1.0) * np.maximum(1.0, np.abs(x[lost]))
     if bounds is not None:
-        lb = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=np.float64)
-        ub = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=np.float64)
+        lb, ub = bounds if isinstance(bounds, tuple) and len(bounds) == 2 and isinstance(bounds[0], np.ndarray) else _bound_arrays(bounds)
         if not np.all((lb == -np.inf) & (ub == np.inf)):
             lower, upper = x - lb, ub - x
             moved = x + h
@@ -68,7 +73,13 @@ class _SiteClassOptimizer:
     model_bounds: list = []
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, init_with_m0: bool = True,
-                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None):
+                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None,
+                 no_clamp: bool = False):
+        # no_clamp: evaluate without the reference's max(f, 1e-300) (CRAB_FLAG_NO_CLAMP).  The default keeps the
+        # reference's arithmetic; on trees of several hundred taxa most site likelihoods lie below 1e-300, the clamped
+        # objective is the constant n_sites * ln(1e-300) with a zero gradient and L-BFGS-B stops where it started --
+        # fits at that size need no_clamp=True (the device's rescaled likelihood is exact there).
+        self.no_clamp = no_clamp
         self.alignment, self.tree = alignment, tree
         self.init_with_m0, self.device, self.engine = init_with_m0, device, engine
         self.rank, self.world_size, self.group = rank, world_size, group
@@ -117,14 +128,26 @@ class _SiteClassOptimizer:
         """The reference's ``compute_log_likelihood`` (e.g. optimizer.py:78-136) for a stack of parameter vectors."""
         params = np.atleast_2d(np.asarray(params, dtype=np.float64))
         # the rows of a stencil mostly share their model parameters (all the branch-length rows do): one model each
-        lead, row_model = np.unique(params[:, :self.n_model], axis=0, return_inverse=True)
-        row_model = row_model.reshape(-1)
+        head = params[:, :self.n_model]
+        same = np.all(head == head[0], axis=1)
+        if same.all():
+            lead, row_model = head[:1], np.zeros(len(params), dtype=np.intp)
+        elif same.sum() + self.n_model >= len(params):      # a stencil: row 0's model, plus one row per model parameter
+            others = np.flatnonzero(~same)
+            lead = np.vstack([head[:1], head[others]])
+            row_model = np.zeros(len(params), dtype=np.intp)
+            row_model[others] = 1 + np.arange(len(others))
+        else:
+            lead, row_model = np.unique(head, axis=0, return_inverse=True)
+            row_model = row_model.reshape(-1)
         distinct = [self.model_at(p) for p in lead]
+        for m in distinct:
+            m.c_quantiles = True        # beta quantiles from the C library (models._beta_quantiles_c)
         cls = [m.get_site_classes() for m in distinct]
         lnl = self.calc.engine.codon_site_classes(np.array([m.kappa for m in distinct], dtype=np.float64)[row_model],
                                                   np.array([c[1] for c in cls], dtype=np.float64)[row_model],
                                                   np.array([c[0] for c in cls], dtype=np.float64)[row_model], self.pi,
-                                                  self._branch_lengths(params))
+                                                  self._branch_lengths(params), no_clamp=self.no_clamp)
         if self.world_size > 1:
             from .dist import ordered_sum_vector
             lnl = ordered_sum_vector(lnl, self.group)
@@ -152,7 +175,7 @@ class _SiteClassOptimizer:
         if self.init_with_m0 and self.optimize_branch_lengths and not isinstance(self, M0Optimizer):   # optimizer.py:346-355
             m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
                              batched_gradient=self.batched_gradient, engine=self.engine, rank=self.rank, world_size=self.world_size,
-                             group=self.group)
+                             group=self.group, no_clamp=self.no_clamp)
             m0.optimize()
             self.n_calls += m0.n_calls
             self.n_vectors += m0.n_vectors
@@ -161,7 +184,8 @@ class _SiteClassOptimizer:
         bounds = list(self.model_bounds) + bb
         self.history = []
         if self.batched_gradient and method == "L-BFGS-B":
-            return minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bounds), x0, jac=True,
+            bound_arrays = _bound_arrays(bounds)
+            return minimize(lambda x: value_and_gradient(self.negative_log_likelihoods, x, bound_arrays), x0, jac=True,
                             method=method, bounds=bounds, options={"maxiter": maxiter})
         return minimize(self.compute_log_likelihood, x0, method=method, bounds=bounds, options={"maxiter": maxiter})
 
@@ -407,9 +431,11 @@ class BranchModelOptimizer:
     are written back to the tree in the boundary's order, i.e. onto the nodes they were evaluated on."""
 
     def __init__(self, alignment, tree, use_f3x4: bool = True, optimize_branch_lengths: bool = True, free_ratio: bool = False,
-                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None):
+                 device: int = 0, batched_gradient: bool = True, engine=None, rank: int = 0, world_size: int = 1, group=None,
+                 no_clamp: bool = False):
         if not optimize_branch_lengths:
             raise NotImplementedError("Global branch scaling not yet implemented")     # as the reference
+        self.no_clamp = no_clamp                                                       # see _SiteClassOptimizer: needed on large trees
         self.rank, self.world_size, self.group = rank, world_size, group
         self.alignment, self.tree, self.use_f3x4, self.free_ratio = alignment, tree, use_f3x4, free_ratio
         self.optimize_branch_lengths, self.batched_gradient = optimize_branch_lengths, batched_gradient
@@ -434,7 +460,8 @@ class BranchModelOptimizer:
         omegas = np.exp(params[:, 1:1 + n_w])
         bl = np.tile(self._template, (len(params), 1))
         bl[:, :-1] = np.exp(params[:, 1 + n_w:])
-        lnl = np.asarray(self.calc.engine.codon_branch(kappa, np.ascontiguousarray(omegas[:, self.model.omega_labels]), self.pi, bl))
+        lnl = np.asarray(self.calc.engine.codon_branch(kappa, np.ascontiguousarray(omegas[:, self.model.omega_labels]), self.pi, bl,
+                                                       no_clamp=self.no_clamp))
         if self.world_size > 1:
             from .dist import ordered_sum_vector
             lnl = ordered_sum_vector(lnl, self.group)
@@ -618,7 +645,7 @@ class M3Optimizer(_SiteClassOptimizer):
         if self.init_with_m0 and self.optimize_branch_lengths:
             m0 = M0Optimizer(self.alignment, self.tree, use_f3x4=self.use_f3x4, optimize_branch_lengths=True, device=self.device,
                              batched_gradient=self.batched_gradient, engine=self.engine, rank=self.rank, world_size=self.world_size,
-                             group=self.group)
+                             group=self.group, no_clamp=self.no_clamp)
             init_kappa, m0_omega, _ = m0.optimize()
             self.n_calls += m0.n_calls
             self.n_vectors += m0.n_vectors

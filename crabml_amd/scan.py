@@ -49,13 +49,20 @@ def lrt_gene(engine, alignment, tree, null: str = "M7", ncatG: int = 10, maxiter
 
 def scan(genes, null: str = "M7", rank: int = 0, world_size: int = 1, workers: int = 8, group=None, make_engine=None, **kw):
     """``genes``: a list of (alignment, tree), the same list on every rank.  Returns the per-gene results in order on
-    every rank; a gene whose fit raises yields ``{"null": ..., "error": message}`` instead of ending the scan (``torch.distributed.all_gather_object`` of this rank's rows when world_size > 1)."""
+    every rank; a gene whose input is unusable yields ``{"null": ..., "error": message}`` instead of ending the scan, a
+    device error (CRAB_ERR_DEVICE) ends it (``torch.distributed.all_gather_object`` of this rank's rows when world_size > 1).
+    Optimiser keywords pass through ``kw`` (e.g. ``no_clamp=True`` for trees of several hundred taxa)."""
     mine = list(gene_shard(len(genes), rank, world_size))
     def one(eng, i):
+        from ._lib import CRAB_ERR_DEVICE, CrabError
         try:
             return lrt_gene(eng, genes[i][0], genes[i][1], null=null, **kw)
-        except Exception as e:   # noqa: BLE001 -- one unusable gene (names that do not match, no codons) must not end a 10 000-gene scan
+        except CrabError as e:
+            if e.status == CRAB_ERR_DEVICE:   # a HIP failure poisons the engine and every gene after it: stop the scan, loudly
+                raise
             return {"null": null, "error": f"{type(e).__name__}: {e}"}
+        except (ValueError, KeyError, IndexError, ArithmeticError) as e:   # one unusable gene (names that do not match, no
+            return {"null": null, "error": f"{type(e).__name__}: {e}"}     # codons) must not end a 10 000-gene scan
 
     rows = map_genes(one, mine, workers=workers, make_engine=make_engine)
     out = [None] * len(genes)

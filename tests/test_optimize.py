@@ -414,3 +414,32 @@ def test_gene_scan_on_the_device():
         assert r["LRT"] >= 0 and 0 <= r["pvalue"] <= 1 and r["fits"]["M8"]["vectors"] > r["fits"]["M8"]["calls"]
     assert mixture[0]["null"] == "M8a" and 0 <= mixture[0]["pvalue"] <= 1
     assert genes[0][1].branch_length.max() == 0.05                   # the caller's trees are left alone
+
+
+@pytest.mark.gpu
+def test_large_tree_fits_need_no_clamp():
+    """500 taxa with long branches: almost every site likelihood lies below 1e-300, so with the reference's clamp the
+    objective is the constant n_sites * ln(1e-300), its finite-difference gradient is zero and L-BFGS-B 'converges'
+    where it starts.  With ``no_clamp=True`` the optimisers see the device's rescaled likelihood: a real gradient,
+    and a fit that moves."""
+    from crabml_amd import optimize, synth
+    case = synth.make_case("M0", 500, 128, seed=9, mean_branch=0.6)
+    aln, tree = synth.as_alignment_and_tree(case)
+    import copy
+    results = {}
+    for no_clamp in (False, True):
+        opt = optimize.M0Optimizer(aln, copy.deepcopy(tree), no_clamp=no_clamp)
+        b0, bb = opt._initial_branch_parameters()
+        x0 = np.array([np.log(2.0), np.log(0.4)] + b0)
+        bounds = list(opt.model_bounds) + bb
+        f, g = optimize.value_and_gradient(opt.negative_log_likelihoods, x0, bounds)
+        results[no_clamp] = (f, g)
+        opt.calc.engine.close()
+    f_c, g_c = results[False]
+    f_x, g_x = results[True]
+    assert abs(f_c - 128 * 690.7755278982137) < 1e-6 * f_c and np.count_nonzero(g_c) == 0
+    assert f_x > 2 * f_c and np.isfinite(f_x) and np.count_nonzero(g_x) == len(g_x) and np.abs(g_x).max() > 1.0
+    opt = optimize.M0Optimizer(aln, copy.deepcopy(tree), no_clamp=True)
+    kappa, omega, lnL = opt.optimize(maxiter=3)
+    assert -lnL < f_x - 1.0 and opt.n_vectors > 3 * len(g_x)      # the fit moved, on whole gradients per call
+    opt.calc.engine.close()
