@@ -53,6 +53,7 @@ SIGNATURES = {
     "crab_last_timing": (C.c_int, [vp, dp, dp, dp]),
     "crab_last_work": (C.c_int, [vp, lp, lp]),
     "crab_last_partial_updates": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "crab_last_tree_parts": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "crab_eig_pool_stats": (C.c_int, [vp, lp, lp, lp]),
     "crab_export_transition_matrices": (C.c_int, [vp, C.c_int, dp]),
     "crab_matrix_exponential": (C.c_int, [C.c_int, C.c_int, dp, dp, C.c_double, dp]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     "crab_build_codon_q_matrix": (C.c_int, [C.c_double, C.c_double, dp, C.c_int, C.c_double, dp]),
     "crab_compile_tree": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compile_path_program": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crab_compile_tree_part": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compress_patterns": (C.c_int, [ip, C.c_int, C.c_int64, C.c_int, lp, dp, lp, lp]),
     "crab_host_pool_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crab_spectral_decompose": (C.c_int, [C.c_int, dp, dp, dp, dp, dp]),

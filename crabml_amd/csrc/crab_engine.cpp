@@ -404,6 +404,8 @@ struct TreeProgram {
     std::vector<std::vector<int>> term_ops;
     std::vector<int> gemm_op_of;
     int n_save_slots = 0;
+    // for tree parts: the ops of the subtree below each internal node are the slice [op_begin, op_fin] of the program
+    std::vector<int> op_begin, op_fin;
 };
 
 // What the kernel needs to know about one program besides its ops.
@@ -415,6 +417,13 @@ struct ProgInfo {
 struct PathProgram {
     std::vector<TreeOp> ops;
     ProgInfo info;
+};
+// A tree cut into subtree programs plus a root program (build_tree_parts).
+struct TreeParts {
+    int target = 0;                       // the part size (products) these cuts were made for
+    std::vector<int> cut;                 // cut nodes; part i saves into slot i
+    std::vector<PathProgram> parts;       // subtree programs
+    PathProgram root;                     // the rest of the tree
 };
 
 struct crab_engine : TreeProgram {
@@ -428,7 +437,10 @@ struct crab_engine : TreeProgram {
     std::vector<DevOp> dev_ops;  // [K][n_ops_pad] programs as last uploaded
     std::vector<int32_t> dev_pidx;  // the (class, node) -> matrix table they were resolved with
     std::vector<int32_t> dev_vec_node;  // ... and which vectors of the batch run path programs (node moved, or -1)
-    int dev_n_whole = 0;                // programs in the first launch (whole walks); the rest are path programs
+    int dev_n_first = 0, dev_n_second = 0;   // programs in the first launch (whole walks, or tree parts) and in the second
+                                             // (path programs, or root programs); 0: one launch
+    int dev_part_target = 0;            // the tree-part size the uploaded programs were cut for (0: uncut)
+    TreeParts tree_parts;
     int64_t dev_gemm_per_pat = 0, dev_leaf_per_pat = 0;
     std::unordered_map<int, PathProgram> path_programs;   // by moved node, built on first use
 
@@ -446,7 +458,7 @@ struct crab_engine : TreeProgram {
     DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls;
     DevBuf<ProgHdr> d_hdr;
     DevBuf<char> d_save;
-    int last_n_path = 0;
+    int last_n_path = 0, last_n_parts = 0;
     DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
     PinBuf<double> h_eig, h_small, h_out;
 
@@ -700,6 +712,9 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
         e->ops.push_back(op);
     };
     std::vector<Frame> fs;
+    e->op_begin.assign(n_nodes, -1);
+    e->op_fin.assign(n_nodes, -1);
+    e->op_begin[e->root] = 0;
     fs.push_back({e->root, 0, 0, false, 0});
     while (!fs.empty()) {
         Frame &f = fs.back();
@@ -707,6 +722,7 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
         if (f.next_child < ic.size()) {
             const size_t i = f.next_child++;
             if (i > 0) e->ops.back().flags |= F_PUSH, e->ops.back().slot = f.depth;  // save the running product
+            e->op_begin[ic[i]] = (int)e->ops.size();
             fs.push_back({ic[i], f.depth + (i > 0 ? 1 : 0), 0, false, 0});
             continue;
         }
@@ -728,6 +744,7 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
         // root: between two normalisations a conditional likelihood passes through at most two products and a
         // handful of sibling multiplications, far from the fp64 exponent range even on tiny branches.
         e->ops.back().flags |= F_FIN | ((height[v] % 2 == 0 || v == e->root) ? F_RESCALE : 0);
+        e->op_fin[v] = (int)e->ops.size() - 1;
         const int depth = f.depth;
         fs.pop_back();
         if (!fs.empty()) {
@@ -846,6 +863,71 @@ void build_path_program(const TreeProgram *e, int node, PathProgram &out)
         cur = p;
     }
     finalise_program(out.ops, out.info);
+}
+
+// Tree parts (a finer work quantum).  A work item of the pruning kernel is a whole-tree walk by one workgroup; when an
+// evaluation has few items per resident workgroup (one GPU's share of a sharded alignment) whole CUs idle or run one
+// workgroup where two would fit.  The tree is then cut below a set of internal nodes: each subtree becomes a program of
+// its own that ends by saving its conditional likelihoods (launch 1: parts x classes x pattern tiles items), and the
+// root program loads them where the subtrees were (launch 2).  The ops, their order and the rescaling points are those
+// of the whole program, so the result is bit-identical.
+void build_tree_parts(const TreeProgram *e, int target, TreeParts &tp)
+{
+    const std::vector<TreeOp> &ops = e->ops;
+    tp = TreeParts{};
+    tp.target = target;
+    auto work = [&](int v) {   // products inside the subtree below v
+        int n = 0;
+        for (int i = e->op_begin[v]; i <= e->op_fin[v]; ++i) n += ops[i].kind == OP_GEMM;
+        return n;
+    };
+    // top-down: a subtree larger than the target gives way to the subtrees of its internal children
+    std::vector<int> frontier{e->root};
+    while (!frontier.empty()) {
+        const int v = frontier.back();
+        frontier.pop_back();
+        const int w = work(v);
+        if (v != e->root && w <= target) {
+            if (w >= 2) tp.cut.push_back(v);     // smaller ones stay in the root program
+            continue;
+        }
+        for (int t : e->term_ops[v])
+            if (ops[t].kind == OP_GEMM) frontier.push_back(ops[t].node);
+    }
+    std::sort(tp.cut.begin(), tp.cut.end(), [&](int a, int b) { return e->op_begin[a] < e->op_begin[b]; });
+    auto plain = [&](int i) {
+        TreeOp o = ops[i];
+        o.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
+        o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
+        return o;
+    };
+    auto transfer = [&](int slot, int flags) {
+        TreeOp o{};
+        o.kind = OP_LOAD;
+        o.node = -1;
+        o.flags = flags;
+        o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
+        o.sv = slot;
+        return o;
+    };
+    tp.parts.resize(tp.cut.size());
+    size_t next = 0;
+    for (int i = 0; i < (int)ops.size();) {
+        if (next < tp.cut.size() && i == e->op_begin[tp.cut[next]]) {
+            const int c = tp.cut[next];
+            PathProgram &pp = tp.parts[next];
+            for (int j = e->op_begin[c]; j <= e->op_fin[c]; ++j) pp.ops.push_back(plain(j));
+            pp.ops.push_back(transfer((int)next, F_SAVE));
+            finalise_program(pp.ops, pp.info);
+            tp.root.ops.push_back(transfer((int)next, 0));      // L_c, where the subtree's ops were
+            i = e->op_fin[c] + 1;
+            ++next;
+        } else {
+            tp.root.ops.push_back(plain(i));
+            ++i;
+        }
+    }
+    finalise_program(tp.root.ops, tp.root.info);
 }
 
 // Packs one program for the device: matrix indices (through pk, the program's node -> matrix table) instead of node
@@ -1055,6 +1137,12 @@ struct EvalPlan {
 bool path_updates_disabled()
 {
     const char *sv = std::getenv("CRAB_NO_PATH_UPDATES");
+    return sv && sv[0] && sv[0] != '0';
+}
+// CRAB_NO_TREE_PARTS=1: never cut the tree of a single evaluation into parts (A/B timing)
+bool tree_parts_disabled()
+{
+    const char *sv = std::getenv("CRAB_NO_TREE_PARTS");
     return sv && sv[0] && sv[0] != '0';
 }
 // Largest save area the partial-update path may allocate (CRAB_PATH_SAVE_GB, default 96 of the 288 GB)
@@ -1269,28 +1357,86 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
         save_bytes = (size_t)e->n_save_slots * Kg * (size_t)n_tiles * 4 * SAVE_TILE_BYTES;
         if (n_path < 4 || save_bytes > path_save_limit_bytes()) n_path = 0;
-        if (n_path > 0) {
-            try {
-                e->d_save.ensure(save_bytes);
-            } catch (const HipError &) {   // no room for the save area: whole walks for everybody
-                (void)hipGetLastError();
-                n_path = 0;
-            }
-        }
         if (n_path == 0) std::fill(vec_node.begin(), vec_node.end(), -1);
     }
+    // ---- tree parts (a finer work quantum): a single evaluation with few work items per resident workgroup is cut into
+    // subtree programs plus a root program (build_tree_parts) ----
+    int part_target = 0;
+    if (G == 1 && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
+        const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device), n_work = n_tiles * pl.K;
+        if (n_work < 6 * slots) {
+            // aim at ~8 items per resident workgroup, at most 16 pieces, pieces of at least 4 products
+            const int64_t pieces = std::min<int64_t>(16, std::max<int64_t>(2, (8 * slots + n_work - 1) / n_work));
+            part_target = (int)std::max<int64_t>(4, (e->n_gemm_edges + pieces - 1) / pieces);
+            if (e->tree_parts.target != part_target) build_tree_parts(e, part_target, e->tree_parts);
+            if (e->tree_parts.cut.empty()) part_target = 0;
+        }
+    }
+    const int n_cut = part_target > 0 ? (int)e->tree_parts.cut.size() : 0;
+    if (n_cut > 0) save_bytes = (size_t)n_cut * Kg * (size_t)n_tiles * 4 * SAVE_TILE_BYTES;
+    if (n_path > 0 || n_cut > 0) {
+        try {
+            e->d_save.ensure(save_bytes);
+        } catch (const HipError &) {   // no room for the save area: whole walks
+            (void)hipGetLastError();
+            n_path = 0;
+            part_target = 0;
+            std::fill(vec_node.begin(), vec_node.end(), -1);
+        }
+    }
+    const int n_parts = part_target > 0 ? n_cut : 0;
+    const int n_prog = pl.K * (1 + n_parts);       // programs 0 .. K-1 write the site likelihoods; part (k, i) is program K + k * n_parts + i
 
     // ---- uploads ----
     const size_t prog_stride = (size_t)dev_ops_padded((int64_t)e->ops.size());
-    if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node) {   // programs depend on the tree and these tables only
-        std::vector<DevOp> progs;
-        std::vector<ProgHdr> hdrs(pl.K);
-        if (n_path == 0) {
-            resolve_programs(e, pl.K, *pidx, progs);
+    if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node || part_target != e->dev_part_target) {
+        // the programs depend on the tree and on these tables only
+        DevOp filler{};
+        filler.w0 = OP_CONST;
+        std::vector<DevOp> progs((size_t)n_prog * prog_stride, filler);
+        std::vector<ProgHdr> hdrs(n_prog);
+        std::vector<int32_t> lists;                 // first launch, then second launch
+        auto header = [&](int prog, const ProgInfo &in, int save_cls, int no_root) {
+            ProgHdr &h = hdrs[prog];
+            h.n_ops = in.n_ops, h.first_gemm_op = in.first_gemm_op, h.first_leaf_row = in.first_leaf_row;
+            h.first_leaf_op = in.first_leaf_op, h.second_leaf_row = in.second_leaf_row, h.third_leaf_row = in.third_leaf_row;
+            h.save_cls = save_cls;
+            h.no_root = no_root;
+        };
+        ProgInfo whole;
+        whole.n_ops = (int)e->ops.size();
+        whole.first_gemm_op = e->first_gemm_op, whole.first_leaf_row = e->first_leaf_row, whole.first_leaf_op = e->first_leaf_op;
+        whole.second_leaf_row = e->second_leaf_row, whole.third_leaf_row = e->third_leaf_row;
+        whole.n_gemm = (int)e->n_gemm_edges, whole.n_leaf = (int)e->n_leaf_edges;
+        int n_first = 0;
+        e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
+        if (n_parts > 0) {
+            const TreeParts &tp = e->tree_parts;
+            for (int k = 0; k < pl.K; ++k) {
+                const int32_t *pk = pidx->data() + (size_t)k * nn;
+                resolve_program(tp.root.ops, pk, false, progs.data() + (size_t)k * prog_stride);
+                header(k, tp.root.info, k, 0);
+                for (int i = 0; i < n_parts; ++i) {
+                    const int prog = pl.K + k * n_parts + i;
+                    resolve_program(tp.parts[i].ops, pk, false, progs.data() + (size_t)prog * prog_stride);
+                    header(prog, tp.parts[i].info, k, 1);
+                }
+            }
+            // launch 1: the parts, longest first, dealt into eight groups of similar total length (the kernel cuts its
+            // work-item order into one chunk per XCD); launch 2: the root programs
+            std::vector<int> order(n_parts);
+            for (int i = 0; i < n_parts; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tp.parts[x].info.n_gemm > tp.parts[y].info.n_gemm; });
+            std::vector<int32_t> all;
+            for (int i : order)
+                for (int k = 0; k < pl.K; ++k) all.push_back(pl.K + k * n_parts + i);
+            for (int g8 = 0; g8 < 8; ++g8)
+                for (size_t i = g8; i < all.size(); i += 8) lists.push_back(all[i]);
+            n_first = (int)lists.size();
+            for (int k = 0; k < pl.K; ++k) lists.push_back(k);
+            e->dev_gemm_per_pat = (int64_t)pl.K * e->n_gemm_edges;
+            e->dev_leaf_per_pat = (int64_t)pl.K * e->n_leaf_edges;
         } else {
-            DevOp filler{};
-            filler.w0 = OP_CONST;
-            progs.assign((size_t)pl.K * prog_stride, filler);
             for (int b = 0; b < G; ++b) {
                 const PathProgram *pp = nullptr;
                 if (vec_node[b] >= 0) {
@@ -1302,33 +1448,18 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                     pp = &it->second;
                 }
                 for (int k = 0; k < Kg; ++k) {
-                    const size_t c = (size_t)b * Kg + k;
-                    resolve_program(pp ? pp->ops : e->ops, pidx->data() + c * nn, b == 0, progs.data() + c * prog_stride);
+                    const int c = b * Kg + k;
+                    resolve_program(pp ? pp->ops : e->ops, pidx->data() + (size_t)c * nn, n_path > 0 && b == 0, progs.data() + (size_t)c * prog_stride);
+                    header(c, pp ? pp->info : whole, k, 0);
                 }
+                e->dev_gemm_per_pat += (int64_t)Kg * (pp ? pp->info.n_gemm : whole.n_gemm);
+                e->dev_leaf_per_pat += (int64_t)Kg * (pp ? pp->info.n_leaf : whole.n_leaf);
             }
-        }
-        ProgInfo whole;
-        whole.n_ops = (int)e->ops.size();
-        whole.first_gemm_op = e->first_gemm_op, whole.first_leaf_row = e->first_leaf_row, whole.first_leaf_op = e->first_leaf_op;
-        whole.second_leaf_row = e->second_leaf_row, whole.third_leaf_row = e->third_leaf_row;
-        for (int b = 0; b < G; ++b) {
-            const ProgInfo &pi_ = vec_node[b] >= 0 ? e->path_programs[vec_node[b]].info : whole;
-            for (int k = 0; k < Kg; ++k) {
-                ProgHdr &h = hdrs[(size_t)b * Kg + k];
-                h.n_ops = pi_.n_ops, h.first_gemm_op = pi_.first_gemm_op, h.first_leaf_row = pi_.first_leaf_row;
-                h.first_leaf_op = pi_.first_leaf_op, h.second_leaf_row = pi_.second_leaf_row, h.third_leaf_row = pi_.third_leaf_row;
-                h.save_cls = k;
-                h.pad = 0;
-            }
-        }
-        // launch lists: whole walks first; path programs in a second launch, dealt into eight groups of similar total
-        // length (one per XCD chunk of the kernel's work-item order)
-        std::vector<int32_t> lists;
-        for (int b = 0; b < G; ++b)
-            if (vec_node[b] < 0)
-                for (int k = 0; k < Kg; ++k) lists.push_back(b * Kg + k);
-        const int n_whole = (int)lists.size();
-        if (n_path > 0) {
+            // launch 1: whole walks; launch 2: path programs, dealt into eight groups of similar total length
+            for (int b = 0; b < G; ++b)
+                if (vec_node[b] < 0)
+                    for (int k = 0; k < Kg; ++k) lists.push_back(b * Kg + k);
+            n_first = (int)lists.size();
             std::vector<int> order;
             for (int b = 0; b < G; ++b)
                 if (vec_node[b] >= 0) order.push_back(b);
@@ -1339,7 +1470,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
         e->dev_pidx = *pidx;
         e->dev_vec_node = vec_node;
-        e->dev_n_whole = n_whole;
+        e->dev_part_target = part_target;
+        e->dev_n_first = n_first;
+        e->dev_n_second = (int)lists.size() - n_first;
         e->d_ops.ensure(progs.size());
         e->d_hdr.ensure(hdrs.size());
         e->d_cls.ensure(lists.size() + 1);
@@ -1348,15 +1481,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         HIP_CHECK(hipMemcpyAsync(e->d_cls.p, lists.data(), lists.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         HIP_CHECK(hipStreamSynchronize(e->stream));  // the sources are pageable
         e->dev_ops.swap(progs);
-        // products and gathers this table executes (per pattern)
-        e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
-        for (int b = 0; b < G; ++b) {
-            const ProgInfo &pi_ = vec_node[b] >= 0 ? e->path_programs[vec_node[b]].info : ProgInfo{};
-            e->dev_gemm_per_pat += (int64_t)Kg * (vec_node[b] >= 0 ? pi_.n_gemm : e->n_gemm_edges);
-            e->dev_leaf_per_pat += (int64_t)Kg * (vec_node[b] >= 0 ? pi_.n_leaf : e->n_leaf_edges);
-        }
     }
-    const int n_whole = e->dev_n_whole, n_path_cls = pl.K - n_whole;
+    const int n_first = e->dev_n_first, n_second = e->dev_n_second;
+    const bool two_launches = n_second > 0;
     // the small per-call inputs travel in one copy: [t_eff M][pi NS][props K][eigensystem slot per matrix, int32 M]
     const size_t n_small = (size_t)M + NS + pl.K + ((size_t)M + 1) / 2;
     e->h_small.ensure(n_small);
@@ -1372,10 +1499,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     double *d_teff = e->d_small.p, *d_pi = d_teff + M, *d_props = d_pi + NS;
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
     e->d_P.ensure((size_t)M * P_ELEMS);
-    const int grid = prune_grid_size(n_tiles * n_whole, e->device);
-    const int grid_path = n_path_cls > 0 ? prune_grid_size(n_tiles * n_path_cls, e->device) : 0;
-    e->d_stack.ensure(prune_stack_doubles(std::max(grid, grid_path), e->max_depth));
-    e->d_stack_e.ensure(prune_stack_ints(std::max(grid, grid_path), e->max_depth));
+    const int grid = prune_grid_size(n_tiles * n_first, e->device);
+    const int grid_second = two_launches ? prune_grid_size(n_tiles * n_second, e->device) : 0;
+    e->d_stack.ensure(prune_stack_doubles(std::max(grid, grid_second), e->max_depth));
+    e->d_stack_e.ensure(prune_stack_ints(std::max(grid, grid_second), e->max_depth));
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_patlnl.ensure((size_t)G * e->n_pat_pad);
@@ -1394,10 +1521,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.n_ops = (int32_t)e->ops.size();
     pa.n_ops_pad = (int32_t)dev_ops_padded((int64_t)e->ops.size());
     pa.P = e->d_P.p;
-    pa.K = n_whole;
-    pa.hdr = n_path_cls > 0 ? e->d_hdr.p : nullptr;
-    pa.cls_list = n_path_cls > 0 ? e->d_cls.p : nullptr;
-    pa.save = n_path_cls > 0 ? (char *)e->d_save.p : nullptr;
+    pa.K = n_first;
+    pa.hdr = two_launches ? e->d_hdr.p : nullptr;
+    pa.cls_list = two_launches ? e->d_cls.p : nullptr;
+    pa.save = two_launches ? (char *)e->d_save.p : nullptr;
     pa.save_K = Kg;
     pa.codes = e->d_codes.p;
     pa.n_pat_pad = e->n_pat_pad;
@@ -1415,10 +1542,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.third_leaf_row = e->third_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
-    if (n_path_cls > 0) {   // the path programs read what vector 0's walk saved: same stream, after it
-        pa.K = n_path_cls;
-        pa.cls_list = e->d_cls.p + n_whole;
-        launch_prune(pa, grid_path, e->stream);
+    if (two_launches) {   // path programs / root programs read what the first launch saved: same stream, after it
+        pa.K = n_second;
+        pa.cls_list = e->d_cls.p + n_first;
+        launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
@@ -1542,7 +1669,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_M = M;
     e->last_dense = e->dev_gemm_per_pat * e->n_pat;     // products and gathers actually executed
     e->last_gather = e->dev_leaf_per_pat * e->n_pat;
-    e->last_n_path = n_path_cls / std::max(1, Kg);
+    e->last_n_path = n_parts > 0 ? 0 : n_second / std::max(1, Kg);
+    e->last_n_parts = n_parts;
 
     if (pl.post_weights) {
         const double *src = e->h_out.p + G;
@@ -1808,6 +1936,7 @@ int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const in
         e->have_tree = false;
         e->dev_ops.clear();
         e->path_programs.clear();
+        e->tree_parts = TreeParts{};
         build_tree(e, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
         e->have_tree = true;
     });
@@ -2157,6 +2286,13 @@ int crab_last_partial_updates(const crab_engine *e, int *n_vectors)
     return CRAB_OK;
 }
 
+int crab_last_tree_parts(const crab_engine *e, int *n_parts)
+{
+    if (!e || !n_parts) return CRAB_ERR_ARG;
+    *n_parts = e->is_multi() ? e->shards[0]->last_n_parts : e->last_n_parts;
+    return CRAB_OK;
+}
+
 int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather_updates)
 {
     if (!e) return CRAB_ERR_ARG;
@@ -2211,6 +2347,30 @@ int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_
             if ((int)ops->size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
             for (size_t i = 0; i < ops->size(); ++i) {
                 const TreeOp &o = (*ops)[i];
+                int32_t *r = ops_out + 6 * i;
+                r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot; r[5] = o.sv;
+            }
+        }
+    });
+}
+
+int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                           int target, int part, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_parts)
+{
+    return guarded(nullptr, [&] {
+        if (target < 1) fail(CRAB_ERR_ARG, "crab_compile_tree_part: target must be >= 1");
+        TreeProgram tp;
+        build_tree(&tp, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        TreeParts parts;
+        build_tree_parts(&tp, target, parts);
+        if (n_parts) *n_parts = (int)parts.cut.size();
+        if (part >= (int)parts.cut.size()) fail(CRAB_ERR_ARG, "crab_compile_tree_part: no such part");
+        const std::vector<TreeOp> &ops = part < 0 ? parts.root.ops : parts.parts[part].ops;
+        if (n_ops) *n_ops = (int)ops.size();
+        if (ops_out) {
+            if ((int)ops.size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
+            for (size_t i = 0; i < ops.size(); ++i) {
+                const TreeOp &o = ops[i];
                 int32_t *r = ops_out + 6 * i;
                 r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot; r[5] = o.sv;
             }

@@ -42,7 +42,8 @@ __host__ __device__ inline int p_gather_index(int i, int j) { return P_IMAGE + j
 // ---- tree program ---------------------------------------------------------------------------
 enum : int32_t {
     OP_GEMM = 0, OP_LEAF = 1, OP_CONST = 2,
-    OP_LOAD = 3   // path programs: the current tile is (or, with F_MUL_PROD, is multiplied by) save slot `sv` of the base pass
+    OP_LOAD = 3   // the current tile is (or, with F_MUL_PROD, is multiplied by) save slot `sv`, written by an earlier launch
+                  // (path programs, root parts); with F_SAVE the other way round: the current tile goes to slot `sv` (tree parts)
 };
 enum : int32_t {
     F_MUL_PROD = 1,   // multiply the new term into the running product of this node
@@ -93,7 +94,7 @@ struct alignas(16) ProgHdr {
     int32_t n_ops;
     int32_t first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row;   // as in PruneArgs
     int32_t save_cls;  // class index inside the save area (the base vector's class with the same rate matrices)
-    int32_t pad;
+    int32_t no_root;   // 1: a tree part -- the program ends by saving its tile (OP_LOAD with F_SAVE), no site likelihood is written
 };
 // Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
 // of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);

@@ -749,10 +749,12 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
                 if (flags & F_MUL_PROD) t_mul<NT, X, Y>();
                 PROF_T(6)
             }
-        } else if (kind == OP_LOAD) {   // path program: a tile the base vector's walk saved
+        } else if (kind == OP_LOAD) {   // a tile another walk saved (path programs, tree parts), or (F_SAVE) saved by this one
             if constexpr (NT == 1) {
                 int es[NT];
-                if (flags & F_MUL_PROD) {
+                if (flags & F_SAVE) {
+                    save_tile<NT, X>(w, sv, eX);
+                } else if (flags & F_MUL_PROD) {
                     load_saved<NT, Y>(w, sv, es);
                     t_mul<NT, X, Y>();
                     eX[0] += es[0];
@@ -836,9 +838,10 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         const long long tile = wi - (long long)ci * n_tiles;
         const int cls = a.cls_list ? a.cls_list[ci] : ci;
         int n_ops = a.n_ops, first_gemm_op = a.first_gemm_op, first_leaf_row = a.first_leaf_row, first_leaf_op = a.first_leaf_op,
-            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls;
+            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls, no_root = 0;
         if (a.hdr) {
             const ProgHdr h = a.hdr[cls];
+            no_root = h.no_root;
             n_ops = h.n_ops, first_gemm_op = h.first_gemm_op, first_leaf_row = h.first_leaf_row, first_leaf_op = h.first_leaf_op;
             second_leaf_row = h.second_leaf_row, third_leaf_row = h.third_leaf_row, save_cls = h.save_cls;
         }
@@ -890,11 +893,11 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         PROF_T(0)
         for (;;) {
             if (walk<NT, X0, X1>(w, e0, e1)) {
-                root_sum<NT, X0>(a, e0, out0, g);
+                if (!no_root) root_sum<NT, X0>(a, e0, out0, g);
                 break;
             }
             if (walk<NT, X1, X0>(w, e1, e0)) {
-                root_sum<NT, X1>(a, e1, out0, g);
+                if (!no_root) root_sum<NT, X1>(a, e1, out0, g);
                 break;
             }
         }

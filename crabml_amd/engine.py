@@ -326,6 +326,12 @@ class Engine:
         self._check(self._lib.crab_last_partial_updates(self._h, C.byref(n)))
         return n.value
 
+    def last_tree_parts(self) -> int:
+        """Subtree programs the last single evaluation was cut into (crab_last_tree_parts); 0: one whole-tree walk per item."""
+        n = C.c_int()
+        self._check(self._lib.crab_last_tree_parts(self._h, C.byref(n)))
+        return n.value
+
     def last_work(self):
         """(dense MFMA updates, gathered leaf updates) of the last evaluation, in pattern x branch x class units."""
         a, b = C.c_int64(), C.c_int64()
@@ -370,6 +376,27 @@ def compile_path_program(parents, leaf_node_ids, node=-1, node_ids=None):
     L.check(lib.crab_compile_path_program(len(par), idp, parp, leafp, len(leaf), int(node), ops.ctypes.data_as(L.ip), n_ops.value,
                                           C.byref(n_ops), C.byref(n_slots)))
     return ops, n_slots.value
+
+
+def compile_tree_parts(parents, leaf_node_ids, target, node_ids=None):
+    """(root program, [subtree programs]) of a tree cut into parts of at most ``target`` products, each int32 [n_ops, 6]."""
+    lib = L.load()
+    par, parp = L.i32(parents)
+    leaf, leafp = L.i32(leaf_node_ids)
+    idp = None
+    if node_ids is not None:
+        ids, idp = L.i32(node_ids)
+
+    def one(part):
+        n_ops, n_parts = C.c_int(), C.c_int()
+        L.check(lib.crab_compile_tree_part(len(par), idp, parp, leafp, len(leaf), int(target), part, None, 0, C.byref(n_ops), C.byref(n_parts)))
+        ops = np.zeros((n_ops.value, 6), dtype=np.int32)
+        L.check(lib.crab_compile_tree_part(len(par), idp, parp, leafp, len(leaf), int(target), part, ops.ctypes.data_as(L.ip), n_ops.value,
+                                           C.byref(n_ops), C.byref(n_parts)))
+        return ops, n_parts.value
+
+    root, n_parts = one(-1)
+    return root, [one(i)[0] for i in range(n_parts)]
 
 
 def compress_patterns(codes, n_states=61):

@@ -207,6 +207,14 @@ int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather
  * whole-tree evaluations per gradient of optimize/optimizer.py:1197-1203. */
 int crab_last_partial_updates(const crab_engine *e, int *n_vectors);
 
+/* Tree parts (a finer work quantum).  A work item of the pruning kernel is one workgroup walking the whole tree for 64
+ * patterns of one class; a single evaluation with fewer than 6 items per resident workgroup (one GPU's share of a
+ * sharded alignment: 392 items for 512 workgroups at BASELINE config 3 over 8 GPUs) is cut below a set of internal nodes
+ * into subtree programs, which run as items of their own and leave their conditional likelihoods in HBM, and a root
+ * program that picks them up in a second launch.  Same ops in the same order: bit-identical results (tested);
+ * CRAB_NO_TREE_PARTS=1 switches it off.  Reports the number of subtree programs of the last evaluation (0: uncut). */
+int crab_last_tree_parts(const crab_engine *e, int *n_parts);
+
 /* Eigensystem pool of this engine since creation: distinct decompositions found resident (hits), decomposed anew
  * (misses), and entries resident now.  Replaces nothing in the reference (it decomposes every matrix on every call,
  * lib.rs:163-169,387-393); lets callers and tests see that a parameter change decomposed only what it had to. */
@@ -247,6 +255,10 @@ int crab_compile_tree(int n_nodes, const int32_t *node_ids, const int32_t *paren
  * 6-field form.  n_save_slots: tiles per (class, pattern tile, wave) the base walk saves. */
 int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids,
                               int n_leaves, int node, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_save_slots);
+/* The programs of a tree cut into parts of at most `target` products (crab_last_tree_parts): part = -1 gives the root
+ * program, part = i the i-th subtree program, in the 6-field form of crab_compile_path_program. */
+int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                           int target, int part, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_parts);
 /* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
 int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
                            int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,

@@ -479,3 +479,45 @@ def test_path_programs_recompute_exactly_what_a_moved_branch_changes():
             assert not (path[:, 2] & 4).any()                       # no stack traffic on a path
     with pytest.raises(ValueError, match="no branch above"):
         compile_path_program([2, 2, -1], [0, 1], node=2)
+
+
+def test_tree_parts_compute_the_whole_tree_walk():
+    """A tree cut into subtree programs plus a root program (the finer work quantum of single evaluations): run through
+    the numpy emulator, parts first, the pieces must reproduce the whole-tree program bit for bit, for every part size."""
+    from crabml_amd.engine import compile_path_program, compile_tree_parts
+    rng = np.random.default_rng(17)
+    n = 5
+    seen_cut = False
+    for trial in range(10):
+        n_leaves = int(rng.integers(4, 60))
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1:
+            k = int(min(len(open_nodes), rng.choice([1, 2, 2, 2, 3])))
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        par = np.array([parent.get(v, -1) for v in range(nxt)], dtype=np.int32)
+        leaf = np.arange(n_leaves, dtype=np.int32)
+        codes = rng.integers(0, n + 1, size=(n_leaves, 6)).astype(np.int32)
+        pi = rng.dirichlet(np.ones(n))
+        P = {v: rng.dirichlet(np.ones(n), size=n) for v in range(nxt)}
+        whole, _ = compile_path_program(par, leaf)
+        want = emulate_program(whole, P, codes, pi, n_states=n)
+        n_gemm = int((whole[:, 0] == 0).sum())
+        for target in (2, 4, 9, 1000):
+            root, parts = compile_tree_parts(par, leaf, target)
+            saved = {}
+            for part in parts:
+                assert (part[-1, 0], part[-1, 2] & 1024) == (3, 1024)          # ends by saving its tile
+                assert 2 <= int((part[:, 0] == 0).sum()) <= target
+                emulate_part = emulate_program(part[:-1], P, codes, pi, n_states=n)   # a well-formed program of its own
+                assert np.isfinite(emulate_part).all()
+                emulate_program(part, P, codes, pi, n_states=n, saved=saved)
+            assert sorted(saved) == list(range(len(parts)))
+            got = emulate_program(root, P, codes, pi, n_states=n, saved=saved)
+            assert np.array_equal(got, want), f"trial {trial}, target {target}"
+            assert int((root[:, 0] == 0).sum()) + sum(int((p[:, 0] == 0).sum()) for p in parts) == n_gemm
+            seen_cut |= len(parts) > 1
+    assert seen_cut

@@ -82,6 +82,9 @@ def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=Fal
             c = codes[arg]
             valid = (c >= 0) & (c < n_states)
             t = np.where(valid[:, None], P_of_node[node].T[np.where(valid, c, 0)], P_of_node[node].sum(axis=1)[None, :])
+        elif kind == OP_LOAD and flags & F_SAVE:          # a tree part hands its tile over
+            saved[sv] = prod
+            continue
         elif kind == OP_LOAD:
             t = saved[sv]
         else:
@@ -101,7 +104,7 @@ def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=Fal
         if flags & F_FIN:
             cur = prod
     assert not stack, "stack not empty at the end of the program"
-    assert cur is prod, "the last op must complete the root"
+    assert cur is prod, "the last op must complete the node"
     return prod @ pi
 
 
