@@ -439,6 +439,7 @@ struct crab_engine : TreeProgram {
     std::vector<int32_t> dev_vec_node;  // ... and which vectors of the batch run path programs (node moved, or -1)
     int dev_n_first = 0, dev_n_second = 0;   // programs in the first launch (whole walks, or tree parts) and in the second
                                              // (path programs, or root programs); 0: one launch
+    int64_t dev_bounds_first[9] = {0}, dev_bounds_second[9] = {0};   // per-XCD chunks of the two launches' work items
     int dev_part_target = 0;            // the tree-part size the uploaded programs were cut for (0: uncut)
     TreeParts tree_parts;
     int64_t dev_gemm_per_pat = 0, dev_leaf_per_pat = 0;
@@ -1364,7 +1365,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     int part_target = 0;
     if (G == 1 && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
         const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device), n_work = n_tiles * pl.K;
-        if (n_work < 6 * slots) {
+        // measured (profiles/r2_tree_parts_timing.txt): a gain below ~3 items per resident workgroup (+15 % at config 3's
+        // per-GPU share, +43 % at config 4's, +10 % at config 4 in full), a small loss at configs[1]'s 3.35
+        if (5 * n_work < 16 * slots) {
             // aim at ~8 items per resident workgroup, at most 16 pieces, pieces of at least 4 products
             const int64_t pieces = std::min<int64_t>(16, std::max<int64_t>(2, (8 * slots + n_work - 1) / n_work));
             part_target = (int)std::max<int64_t>(4, (e->n_gemm_edges + pieces - 1) / pieces);
@@ -1427,11 +1430,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             std::vector<int> order(n_parts);
             for (int i = 0; i < n_parts; ++i) order[i] = i;
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tp.parts[x].info.n_gemm > tp.parts[y].info.n_gemm; });
-            std::vector<int32_t> all;
-            for (int i : order)
-                for (int k = 0; k < pl.K; ++k) all.push_back(pl.K + k * n_parts + i);
-            for (int g8 = 0; g8 < 8; ++g8)
-                for (size_t i = g8; i < all.size(); i += 8) lists.push_back(all[i]);
+            for (int k = 0; k < pl.K; ++k)        // class-major (the matrices of one class stay together), longest parts first
+                for (int i : order) lists.push_back(pl.K + k * n_parts + i);
             n_first = (int)lists.size();
             for (int k = 0; k < pl.K; ++k) lists.push_back(k);
             e->dev_gemm_per_pat = (int64_t)pl.K * e->n_gemm_edges;
@@ -1464,10 +1464,39 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             for (int b = 0; b < G; ++b)
                 if (vec_node[b] >= 0) order.push_back(b);
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return hdrs[(size_t)x * Kg].n_ops > hdrs[(size_t)y * Kg].n_ops; });
-            for (int g8 = 0; g8 < 8; ++g8)
-                for (size_t i = g8; i < order.size(); i += 8)
-                    for (int k = 0; k < Kg; ++k) lists.push_back(order[i] * Kg + k);
+            for (int k = 0; k < Kg; ++k)          // class-major, longest paths first
+                for (int b : order) lists.push_back(b * Kg + k);
         }
+        // One chunk of the work-item order per XCD, of equal work rather than equal item count: the programs of a launch
+        // differ in length (a product costs about ten leaf edges; every item pays a fixed prologue).
+        auto bounds = [&](int lo, int hi, int64_t *out) {
+            std::vector<double> w(hi - lo);
+            double total = 0.0;
+            for (int i = lo; i < hi; ++i) {
+                const ProgHdr &h = hdrs[lists[i]];
+                int n_gemm = 0;
+                const DevOp *po = progs.data() + (size_t)lists[i] * prog_stride;
+                for (int j = 0; j < h.n_ops; ++j) n_gemm += (po[j].w0 & 3) == OP_GEMM;
+                w[i - lo] = 1.0 + n_gemm + 0.1 * (h.n_ops - n_gemm);
+                total += w[i - lo] * (double)n_tiles;
+            }
+            out[0] = 0;
+            double acc = 0.0;
+            int x = 1;
+            for (int i = lo; i < hi && x < 8; ++i) {
+                // cut inside this program's run of tiles wherever a boundary falls
+                while (x < 8 && acc + w[i - lo] * (double)n_tiles >= total * x / 8.0) {
+                    const double need = total * x / 8.0 - acc;
+                    out[x++] = (int64_t)(i - lo) * n_tiles + std::min<int64_t>(n_tiles, (int64_t)std::llround(need / w[i - lo]));
+                }
+                acc += w[i - lo] * (double)n_tiles;
+            }
+            while (x < 8) out[x++] = (int64_t)(hi - lo) * n_tiles;
+            out[8] = (int64_t)(hi - lo) * n_tiles;
+            for (int y = 1; y <= 8; ++y) out[y] = std::max(out[y], out[y - 1]);
+        };
+        bounds(0, n_first, e->dev_bounds_first);
+        bounds(n_first, (int)lists.size(), e->dev_bounds_second);
         e->dev_pidx = *pidx;
         e->dev_vec_node = vec_node;
         e->dev_part_target = part_target;
@@ -1526,6 +1555,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.cls_list = two_launches ? e->d_cls.p : nullptr;
     pa.save = two_launches ? (char *)e->d_save.p : nullptr;
     pa.save_K = Kg;
+    std::copy(e->dev_bounds_first, e->dev_bounds_first + 9, pa.xcd_bounds);
     pa.codes = e->d_codes.p;
     pa.n_pat_pad = e->n_pat_pad;
     pa.pi_pad = d_pi;
@@ -1545,6 +1575,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     if (two_launches) {   // path programs / root programs read what the first launch saved: same stream, after it
         pa.K = n_second;
         pa.cls_list = e->d_cls.p + n_first;
+        std::copy(e->dev_bounds_second, e->dev_bounds_second + 9, pa.xcd_bounds);
         launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));

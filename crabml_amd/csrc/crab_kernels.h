@@ -130,6 +130,8 @@ struct PruneArgs {
     int32_t *out_e;           // [K][n_pat_pad]  power-of-two exponent: f = out_f * 2^out_e
     const ProgHdr *hdr;       // [number of programs] per-program headers, or nullptr: n_ops and the five fields below apply to all
     const int32_t *cls_list;  // programs (= rows of out_f) this launch walks, or nullptr: 0 .. K-1
+    int64_t xcd_bounds[9];    // with cls_list: work items [xcd_bounds[x], xcd_bounds[x + 1]) go to XCD x's workgroups (chunks of
+                              // equal WORK, set by the host from the programs' lengths; the kernel's own cut is by item count)
     char *save;               // save area, or nullptr
     int32_t save_K;           // classes in the save area
     int32_t first_gemm_op;    // index of the first GEMM op (-1 if none)

@@ -832,7 +832,8 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
-    const long long chunk_lo = n_work * xcd / N_XCD, chunk_hi = n_work * (xcd + 1) / N_XCD;
+    const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
+    const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
     for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
         const int ci = (int)(wi / n_tiles);
         const long long tile = wi - (long long)ci * n_tiles;

@@ -208,7 +208,7 @@ int crab_last_work(const crab_engine *e, int64_t *dense_updates, int64_t *gather
 int crab_last_partial_updates(const crab_engine *e, int *n_vectors);
 
 /* Tree parts (a finer work quantum).  A work item of the pruning kernel is one workgroup walking the whole tree for 64
- * patterns of one class; a single evaluation with fewer than 6 items per resident workgroup (one GPU's share of a
+ * patterns of one class; a single evaluation with fewer than 3.2 items per resident workgroup (one GPU's share of a
  * sharded alignment: 392 items for 512 workgroups at BASELINE config 3 over 8 GPUs) is cut below a set of internal nodes
  * into subtree programs, which run as items of their own and leave their conditional likelihoods in HBM, and a root
  * program that picks them up in a second launch.  Same ops in the same order: bit-identical results (tested);
