@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrabml_amd.so")
+LIB_PATH = os.environ.get("CRAB_AMD_LIB") or os.path.join(_HERE, "libcrabml_amd.so")   # the override is for same-box A/B timing of two builds
 
 CRAB_OK, CRAB_ERR_ARG, CRAB_ERR_NO_ROOT, CRAB_ERR_EIGEN, CRAB_ERR_DEVICE, CRAB_ERR_STATE = range(6)
 CRAB_FLAG_NO_CLAMP = 1

@@ -137,6 +137,13 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // busiest frame depths; on trees of Sethi-Ullman depth <= 2 no conditional likelihood ever leaves the register
 // file.  The other slots (and every slot with NT = 2) go to the global-memory stack.
 constexpr int N_XCD = 8;  // the launch grid is a multiple of this
+// -DCRAB_NO_PATH_OPS compiles the save / load ops of partial updates and tree parts out of the kernel (same-box A/B of
+// what their presence costs a plain walk; such a build must run with CRAB_NO_PATH_UPDATES=1 CRAB_NO_TREE_PARTS=1)
+#ifdef CRAB_NO_PATH_OPS
+constexpr bool PATH_OPS = false;
+#else
+constexpr bool PATH_OPS = true;
+#endif
 
 template <int NT>
 struct Plan {
@@ -649,7 +656,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
         const int w0 = __builtin_amdgcn_readlane(w.batch.w0, il);
         const int kind = w0 & 3, flags = (w0 >> 2) & ((1 << OP_FLAG_BITS) - 1), slot = w0 >> (2 + OP_FLAG_BITS);
         int sv = 0;
-        if constexpr (NT == 1) sv = __builtin_amdgcn_readlane(w.batch.sv, il);
+        if constexpr (NT == 1 && PATH_OPS) sv = __builtin_amdgcn_readlane(w.batch.sv, il);
         const int mat = __builtin_amdgcn_readlane(w.batch.mat, il);
         const int arg = __builtin_amdgcn_readlane(w.batch.arg, il);
         int pre_mat = -1, pre_row2 = -1, pre_mat_b = -1, pre_row3 = -1;
@@ -669,7 +676,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             PROF_T(1)
             __syncthreads();
             PROF_T(2)
-            if constexpr (NT == 1)
+            if constexpr (NT == 1 && PATH_OPS)
                 if (flags & F_SAVE) save_tile<NT, X>(w, sv, eX);   // the operand of this edge's product
             Ride<(PRE ? G : -1), X> ride;
             ride.dma_src = arg >= 0 ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
@@ -692,7 +699,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             w.buf ^= 1;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) eY[nt] = eX[nt];
-            if constexpr (NT == 1) {
+            if constexpr (NT == 1 && PATH_OPS) {
                 if ((flags & (F_SAVE | F_POP_MUL)) == (F_SAVE | F_POP_MUL)) save_tile<NT, Y>(w, sv + 2, eY);   // the edge's message
                 if (flags & F_POP_SAVED) {                     // path program: the running product the base walk saved
                     int es[NT];
@@ -708,7 +715,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             PROF_T(4)
             if (flags & F_RESCALE) t_normalise<NT, Y>(eY);
             PROF_T(7)
-            if constexpr (NT == 1)
+            if constexpr (NT == 1 && PATH_OPS)
                 if ((flags & (F_SAVE | F_FIN)) == F_SAVE) save_tile<NT, Y>(w, sv + 1, eY);   // the parent's running product
             if (flags & F_PUSH) push<NT, Y>(w, slot, eY);
             PROF_T(8)
@@ -750,7 +757,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
                 PROF_T(6)
             }
         } else if (kind == OP_LOAD) {   // a tile another walk saved (path programs, tree parts), or (F_SAVE) saved by this one
-            if constexpr (NT == 1) {
+            if constexpr (NT == 1 && PATH_OPS) {
                 int es[NT];
                 if (flags & F_SAVE) {
                     save_tile<NT, X>(w, sv, eX);
@@ -971,7 +978,7 @@ static int blocks_per_cu()
 int prune_tile_width() { return 64 * chosen_nt(); }
 int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }
 bool prune_has_prefetch() { return chosen_nt() == 1 ? Plan<1>::HAS_PRE : Plan<2>::HAS_PRE; }
-bool prune_supports_paths() { return chosen_nt() == 1; }
+bool prune_supports_paths() { return chosen_nt() == 1 && PATH_OPS; }
 
 int prune_grid_size(int64_t n_work, int device)
 {
