@@ -28,6 +28,7 @@ SIGNATURES = {
     "crab_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "crab_create_multi": (C.c_int, [ip, C.c_int, C.POINTER(vp)]),
     "crab_n_devices": (C.c_int, [vp]),
+    "crab_set_eigensolver": (C.c_int, [vp, C.c_int]),
     "crab_destroy": (None, [vp]),
     "crab_last_error": (C.c_char_p, [vp]),
     "crab_device_available": (C.c_int, []),

@@ -461,7 +461,9 @@ struct crab_engine : TreeProgram {
     DevBuf<char> d_save;
     int last_n_path = 0, last_n_parts = 0;
     DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
-    PinBuf<double> h_eig, h_small, h_out;
+    PinBuf<double> h_eig, h_small, h_out, h_S;
+    DevBuf<double> d_S;
+    bool device_eigen = false;   // decompose on the device (kernel 0) instead of on the host: crab_set_eigensolver
 
     EigPool eig_pool;
     int64_t eig_hits = 0, eig_misses = 0;
@@ -490,7 +492,7 @@ struct crab_engine : TreeProgram {
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
         d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
-        h_eig.release(); h_small.release(); h_out.release();
+        h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (ev_k0) (void)hipEventDestroy(ev_k0);
@@ -1239,7 +1241,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     e->eig_hits += n_uniq - (int)todo.size();
     e->eig_misses += (int)todo.size();
-    e->h_eig.ensure(todo.size() * EIG_STRIDE);
+    const bool device_eigen = e->device_eigen && !todo.empty();
+    e->h_eig.ensure(device_eigen ? 1 : todo.size() * EIG_STRIDE);
     double *h_eig = e->h_eig.p;
     std::vector<char> ok(todo.size(), 1);
     std::vector<double> Qbuilt(by_params ? todo.size() * (size_t)n * n : 0);
@@ -1253,7 +1256,40 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
         ok[j] = spectral_decompose(n, Qi, pi, h_eig + (size_t)j * EIG_STRIDE) ? 1 : 0;
     };
-    if (e->shared_eig) {   // a shard of a multi-device handle: every shard needs this matrix, one of them decomposes it
+    if (device_eigen) {
+        // The device decomposes (kernel 0): the host only symmetrises, S = Pi^1/2 Q Pi^-1/2 from the lower triangle like
+        // eigh(UPLO::Lower) (matrix.rs:42-54), padded to 64 x 64, and ships it with the slot list and sqrt(pi).
+        const size_t per = (size_t)NS * NS, n_todo = todo.size();
+        e->h_S.ensure(n_todo * per + NS + (n_todo + 1) / 2 + 1);
+        double *hS = e->h_S.p;
+        std::vector<double> sq(n), isq(n);
+        for (int i = 0; i < n; ++i) {
+            if (!(pi[i] > 0.0)) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed: pi has a non-positive entry");
+            sq[i] = std::sqrt(pi[i]);
+            isq[i] = 1.0 / sq[i];
+        }
+        parallel_for((int)n_todo, [&](int j) {
+            const int i0 = uniq_src[todo[j]];
+            const double *Qi = Q + (size_t)i0 * n * n;
+            std::vector<double> built;
+            if (by_params) {
+                built.resize((size_t)n * n);
+                crab_build_codon_q_matrix(pl.kw[i0].first, pl.kw[i0].second, pi, 1, 1.0, built.data());
+                Qi = built.data();
+            }
+            double *Sj = hS + (size_t)j * per;
+            std::memset(Sj, 0, per * sizeof(double));
+            bool finite = true;
+            for (int a = 0; a < n; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    const double v = sq[a] * Qi[(size_t)a * n + b] * isq[b];
+                    finite = finite && std::isfinite(v);
+                    Sj[(size_t)a * NS + b] = v;
+                    Sj[(size_t)b * NS + a] = v;
+                }
+            ok[j] = finite ? 1 : 0;
+        });
+    } else if (e->shared_eig) {   // a shard of a multi-device handle: every shard needs this matrix, one of them decomposes it
         SharedEigCache *sc = e->shared_eig;
         parallel_for((int)todo.size(), [&](int j) {
             const int i = uniq_src[todo[j]];
@@ -1276,7 +1312,22 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         std::vector<int> &got;
         ~SlotGuard() { pool.give_back(got); }
     } slot_guard{pool, new_slots};
-    if (!todo.empty()) {
+    const double *d_eig_S = nullptr, *d_eig_sqrt_pi = nullptr;
+    const int32_t *d_eig_slots = nullptr;
+    if (device_eigen) {
+        pool.allocate((int)todo.size(), new_slots, e->stream);
+        const size_t per = (size_t)NS * NS, n_todo = todo.size(), n_d = n_todo * per + NS + (n_todo + 1) / 2 + 1;
+        double *hS = e->h_S.p, *h_sq = hS + n_todo * per;
+        for (int i = 0; i < NS; ++i) h_sq[i] = i < n ? std::sqrt(pi[i]) : 0.0;
+        int32_t *h_slots = reinterpret_cast<int32_t *>(h_sq + NS);
+        for (size_t j = 0; j < n_todo; ++j) h_slots[j] = new_slots[j];
+        e->d_S.ensure(n_d);
+        HIP_CHECK(hipMemcpyAsync(e->d_S.p, hS, n_d * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        d_eig_S = e->d_S.p;
+        d_eig_sqrt_pi = e->d_S.p + n_todo * per;
+        d_eig_slots = reinterpret_cast<const int32_t *>(e->d_S.p + n_todo * per + NS);
+        for (size_t j = 0; j < todo.size(); ++j) pool_slot[todo[j]] = new_slots[j];
+    } else if (!todo.empty()) {
         pool.allocate((int)todo.size(), new_slots, e->stream);
         // consecutive slots travel in one copy (a first call fills a fresh pool front to back)
         for (size_t j = 0; j < todo.size();) {
@@ -1543,6 +1594,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
+    if (device_eigen) launch_eigen(d_eig_S, d_eig_slots, d_eig_sqrt_pi, pool.d, (int)todo.size(), n, e->stream);
     launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, M, n, true, e->stream);
 
     PruneArgs pa{};
@@ -1916,6 +1968,7 @@ int crab_create(int device, crab_engine **out)
         HIP_CHECK(hipEventCreate(&e->ev_end));
         HIP_CHECK(hipEventCreate(&e->ev_k0));
         HIP_CHECK(hipEventCreate(&e->ev_k1));
+        if (const char *sv = std::getenv("CRAB_DEVICE_EIGEN")) e->device_eigen = sv[0] && sv[0] != '0';
     });
     if (rc == CRAB_OK) *out = e.release();
     return rc;
@@ -1943,6 +1996,14 @@ int crab_create_multi(const int *devices, int n_devices, crab_engine **out)
     e->workers.reset(new ShardWorkers());
     e->workers->start(n_devices - 1);
     *out = e.release();
+    return CRAB_OK;
+}
+
+int crab_set_eigensolver(crab_engine *e, int on_device)
+{
+    if (!e) return CRAB_ERR_ARG;
+    e->device_eigen = on_device != 0;
+    for (crab_engine *sh : e->shards) sh->device_eigen = on_device != 0;
     return CRAB_OK;
 }
 

@@ -111,6 +111,13 @@ inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 +
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
                     bool clamp_negative, hipStream_t stream);
 
+// ---- kernel 0: batched spectral decomposition on the device  (replaces matrix.rs:31-75 where many matrices change per
+// call: free-ratio fits, gene scans; the host solver of crab_eigen.cpp stays the default) ----------------------------
+// For m in [0, M): S + m*NS*NS is the symmetrised rate matrix Pi^1/2 Q Pi^-1/2, padded with zeros to 64 x 64; the packed
+// eigensystem (crab_eigen.h layout: U^T, U^-1, lambda) is written to pool + slot[m]*EIG_STRIDE.  One workgroup per
+// matrix: parallel cyclic Jacobi in LDS, then one Newton-Schulz step on the eigenvectors.  sqrt_pi: [64], zero beyond n.
+void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream);
+
 // ---- kernel 2: Felsenstein pruning, whole tree per (pattern tile, class)  ---------------------
 // (replaces likelihood.rs:120-132,176-246 and branch_site_likelihood.rs:222-299)
 struct PruneArgs {

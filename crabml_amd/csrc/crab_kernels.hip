@@ -118,6 +118,178 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 }
 
 // =============================================================================================
+// kernel 0: batched symmetric eigensolver (parallel cyclic Jacobi in LDS)
+// =============================================================================================
+// One workgroup (256 threads) per matrix.  A (the matrix, overwritten) and V (the accumulated rotations) live in LDS
+// with a row stride of 65 doubles (column walks hit different banks).  A sweep is 63 steps of 32 disjoint pairs (p, q)
+// (round-robin tournament over 64 indices); a step computes the 32 rotations, applies them to the columns of A and V,
+// then to the rows of A.  Indices beyond n_states are padding: their rows and columns are exact zeros, their pairs are
+// skipped, so they never mix with the real ones.  Sweeps stop when one passes without a rotation (off-diagonal
+// entries below 2^-53 of the geometric mean of their diagonal entries), at most 24.  Then one Newton-Schulz step
+// V <- V (3 I - V^T V) / 2 (crab_eigen.cpp:reorthogonalise has the reason), and the result is packed for kernel 1.
+constexpr int EJ_N = NS - 1;   // at most 63 states: index 63 is always padding and is not stored
+constexpr int EJ_LD = EJ_N;    // LDS row stride in doubles (odd: column walks spread over the banks); 2 x 31 752 B + tables < 64 KiB
+
+__global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S, const int32_t *__restrict__ slot,
+                                                    const double *__restrict__ sqrt_pi, double *__restrict__ pool, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *A = reinterpret_cast<double *>(smem_raw);           // [63][EJ_LD]
+    double *V = A + EJ_N * EJ_LD;                               // [63][EJ_LD]
+    double *rc = V + EJ_N * EJ_LD;                              // [32] cosines
+    double *rs = rc + 32;                                       // [32] sines
+    int *rp = reinterpret_cast<int *>(rs + 32);                 // [32] p, [32] q
+    int *rq = rp + 32;
+    int *n_rot = rq + 32;                                       // rotations made in the current sweep
+    const int t = threadIdx.x;
+    const double *Sm = S + (size_t)blockIdx.x * NS * NS;
+    for (int idx = t; idx < EJ_N * EJ_N; idx += 256) {
+        const int i = idx / EJ_N, j = idx - i * EJ_N;
+        A[i * EJ_LD + j] = Sm[i * NS + j];
+        V[i * EJ_LD + j] = i == j ? 1.0 : 0.0;
+    }
+    if (t == 0) *n_rot = 0;
+    __syncthreads();
+
+    const int k = t >> 3, r = t & 7;       // pair handled by this thread, and its share of the rows / columns
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        for (int step = 0; step < 63; ++step) {
+            if (t < 32) {
+                int p, q;
+                if (t == 0) {
+                    p = 63, q = step;      // the bye: index 63 does not exist
+                } else {
+                    p = (step + t) % 63, q = (step - t + 63) % 63;
+                }
+                if (p > q) {
+                    const int x = p;
+                    p = q, q = x;
+                }
+                double c = 1.0, sn = 0.0;
+                if (q < n) {
+                    const double app = A[p * EJ_LD + p], aqq = A[q * EJ_LD + q], apq = A[p * EJ_LD + q];
+                    if (apq != 0.0 && fabs(apq) > 1.1102230246251565e-16 * sqrt(fabs(app) * fabs(aqq))) {
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + tt * tt);
+                        sn = tt * c;
+                        atomicAdd(n_rot, 1);
+                    } else if (apq != 0.0) {
+                        A[p * EJ_LD + q] = 0.0;    // negligible: drop it (both copies) so that it cannot creep back
+                        A[q * EJ_LD + p] = 0.0;
+                    }
+                }
+                rc[t] = c, rs[t] = sn, rp[t] = p, rq[t] = q;
+            }
+            __syncthreads();
+            const double c = rc[k], sn = rs[k];
+            const int p = rp[k], q = rq[k];
+            if (sn != 0.0) {   // columns p and q of A and of V:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int i = r + 8 * m;
+                    if (i < n) {
+                        const double ap = A[i * EJ_LD + p], aq = A[i * EJ_LD + q];
+                        A[i * EJ_LD + p] = c * ap - sn * aq;
+                        A[i * EJ_LD + q] = sn * ap + c * aq;
+                        const double vp = V[i * EJ_LD + p], vq = V[i * EJ_LD + q];
+                        V[i * EJ_LD + p] = c * vp - sn * vq;
+                        V[i * EJ_LD + q] = sn * vp + c * vq;
+                    }
+                }
+            }
+            __syncthreads();
+            if (sn != 0.0) {   // rows p and q of A
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int j = r + 8 * m;
+                    if (j < n) {
+                        const double ap = A[p * EJ_LD + j], aq = A[q * EJ_LD + j];
+                        A[p * EJ_LD + j] = c * ap - sn * aq;
+                        A[q * EJ_LD + j] = sn * ap + c * aq;
+                    }
+                }
+            }
+            __syncthreads();
+            if (sn != 0.0 && r == 0) {   // the rotated pair is diagonal now, exactly
+                A[p * EJ_LD + q] = 0.0;
+                A[q * EJ_LD + p] = 0.0;
+            }
+            // (only entries (p, q) / (q, p) are touched here: no pair of the next step reads them before the barrier
+            //  that follows its rotation computation -- every pair meets once per sweep)
+        }
+        __syncthreads();
+        const int made = *n_rot;
+        __syncthreads();
+        if (t == 0) *n_rot = 0;
+        __syncthreads();                    // the reset lands before the next sweep's first count
+        if (made == 0) break;
+    }
+    __syncthreads();
+
+    // ---- Newton-Schulz: E = (I - V^T V) / 2 into A's storage (eigenvalues saved first), then V += V E ----
+    double *lam = rc;                       // 64 doubles: rc and rs are contiguous
+    if (t < NS) lam[t] = t < n ? A[t * EJ_LD + t] : 0.0;
+    __syncthreads();
+    {
+        const int kk = t >> 2, l0 = (t & 3) * 16;    // 16 entries of row kk of G = V^T V
+        double g[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) g[x] = 0.0;
+        if (kk < n)
+            for (int i = 0; i < n; ++i) {
+                const double vk = V[i * EJ_LD + kk];
+#pragma unroll
+                for (int x = 0; x < 16; ++x)
+                    if (l0 + x < EJ_N) g[x] += vk * V[i * EJ_LD + l0 + x];
+            }
+        __syncthreads();
+        if (kk < EJ_N)
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                if (l0 + x < EJ_N) A[kk * EJ_LD + l0 + x] = (kk < n && l0 + x < n) ? 0.5 * ((kk == l0 + x ? 1.0 : 0.0) - g[x]) : 0.0;
+    }
+    __syncthreads();
+    {
+        const int i = t >> 2, l0 = (t & 3) * 16;     // 16 entries of row i of V E
+        double w[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) w[x] = 0.0;
+        if (i < n)
+            for (int kk = 0; kk < n; ++kk) {
+                const double vik = V[i * EJ_LD + kk];
+#pragma unroll
+                for (int x = 0; x < 16; ++x)
+                    if (l0 + x < EJ_N) w[x] += vik * A[kk * EJ_LD + l0 + x];
+            }
+        __syncthreads();                    // all reads of V done before anybody updates it
+        if (i < n)
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                if (l0 + x < n) V[i * EJ_LD + l0 + x] += w[x];
+    }
+    __syncthreads();
+
+    // ---- pack: U^T[k][i] = V[i][k] / sqrt(pi_i), U^-1[k][j] = V[j][k] sqrt(pi_j), lambda[k]; zero on the padding ----
+    double *out = pool + (size_t)slot[blockIdx.x] * EIG_STRIDE;
+    for (int idx = t; idx < NS * NS; idx += 256) {
+        const int kk = idx >> 6, i = idx & 63;
+        const bool real = kk < n && i < n;
+        const double v = real ? V[i * EJ_LD + kk] : 0.0, sq = real ? sqrt_pi[i] : 1.0;
+        out[EIG_UT + idx] = real ? v / sq : 0.0;
+        out[EIG_UINV + idx] = real ? v * sq : 0.0;
+    }
+    if (t < NS) out[EIG_LAM + t] = lam[t];
+}
+
+void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream)
+{
+    if (M <= 0) return;
+    const size_t lds = (size_t)(2 * EJ_N * EJ_LD + 64) * sizeof(double) + 65 * sizeof(int);
+    hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), lds, stream, S, slot, sqrt_pi, pool, n_states);
+}
+
+// =============================================================================================
 // kernel 2: pruning
 // =============================================================================================
 // Register plan.  The conditional-likelihood tiles are the only large state of the walk, they live for the whole

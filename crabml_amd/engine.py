@@ -81,6 +81,11 @@ class Engine:
         self.n_states = int(n_states)
         self.n_sites = codes_.shape[1]
 
+    def set_eigensolver(self, where: str):
+        """"host" (default: shortest latency for a few matrices) or "device" (many matrices per call: free-ratio fits,
+        gene scans); crab_set_eigensolver."""
+        self._check(self._lib.crab_set_eigensolver(self._h, {"host": 0, "device": 1}[where]))
+
     @property
     def n_devices(self) -> int:
         return int(self._lib.crab_n_devices(self._h))

@@ -74,6 +74,14 @@ int crab_create(int device, crab_engine **out);
  * the shard that owns the site.  The handle is used like any other engine with every function below; a device may be
  * listed more than once (several shards on one GPU).  n_devices in [1, 64]. */
 int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
+/* Where CachedQMatrix::new (matrix.rs:31-75) runs.  0 (default): on the host, one task per matrix (0.25 ms for the 11
+ * matrices of an M8 evaluation: the shortest latency when few matrices change per call).  1: on the device, one
+ * workgroup per matrix (parallel cyclic Jacobi in LDS + one re-orthogonalisation step; no host work beyond symmetrising
+ * the matrix, no synchronisation): for callers that change many rate matrices per call -- free-ratio fits (1 998 per
+ * kappa row at 1000 taxa), gene scans with several engines per GPU (43 per gradient call each).  Results of the two
+ * solvers agree to the accuracy of either (P entries within 2e-14); within one setting batched and single evaluations
+ * stay bit-identical.  The environment variable CRAB_DEVICE_EIGEN=1 sets the default of new engines. */
+int crab_set_eigensolver(crab_engine *e, int on_device);
 /* Shards behind a handle: 1 for crab_create, n_devices for crab_create_multi. */
 int crab_n_devices(const crab_engine *e);
 void crab_destroy(crab_engine *e);
