@@ -121,9 +121,9 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // kernel 0: batched symmetric eigensolver (parallel cyclic Jacobi in LDS)
 // =============================================================================================
 // One workgroup (256 threads) per matrix.  A (the matrix, overwritten) and V (the accumulated rotations) live in LDS
-// with a row stride of 65 doubles (column walks hit different banks).  A sweep is 63 steps of 32 disjoint pairs (p, q)
+// with a row stride of 63 doubles (odd: column walks spread over the banks).  A sweep is 63 steps of 32 disjoint pairs (p, q)
 // (round-robin tournament over 64 indices); a step computes the 32 rotations, applies them to the columns of A and V,
-// then to the rows of A.  Indices beyond n_states are padding: their rows and columns are exact zeros, their pairs are
+// then (one barrier later) to the rows of A.  Indices beyond n_states are padding: their rows and columns are exact zeros, their pairs are
 // skipped, so they never mix with the real ones.  Sweeps stop when one passes without a rotation (off-diagonal
 // entries below 2^-53 of the geometric mean of their diagonal entries), at most 24.  Then one Newton-Schulz step
 // V <- V (3 I - V^T V) / 2 (crab_eigen.cpp:reorthogonalise has the reason), and the result is packed for kernel 1.
@@ -136,11 +136,8 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *A = reinterpret_cast<double *>(smem_raw);           // [63][EJ_LD]
     double *V = A + EJ_N * EJ_LD;                               // [63][EJ_LD]
-    double *rc = V + EJ_N * EJ_LD;                              // [32] cosines
-    double *rs = rc + 32;                                       // [32] sines
-    int *rp = reinterpret_cast<int *>(rs + 32);                 // [32] p, [32] q
-    int *rq = rp + 32;
-    int *n_rot = rq + 32;                                       // rotations made in the current sweep
+    double *lam = V + EJ_N * EJ_LD;                             // [64] eigenvalues, once the sweeps are done
+    int *n_rot = reinterpret_cast<int *>(lam + NS);             // rotations made in the current sweep
     const int t = threadIdx.x;
     const double *Sm = S + (size_t)blockIdx.x * NS * NS;
     for (int idx = t; idx < EJ_N * EJ_N; idx += 256) {
@@ -151,48 +148,39 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
     if (t == 0) *n_rot = 0;
     __syncthreads();
 
-    const int k = t >> 3, r = t & 7;       // pair handled by this thread, and its share of the rows / columns
+    // Thread t works for pair k on rows / columns r, r + 8, ...  The four pairs of a half-wave are 8 apart, so that
+    // their columns (row stride 63 = -1 mod 32 bank pairs) fall into different banks.  The 8 threads of a pair sit in
+    // one wave and each computes the pair's rotation itself: no table, no barrier before the column update (a pair's
+    // threads read a_pp, a_qq, a_pq in lockstep before any of them writes, and no other pair touches columns p, q).
+    const int g = t >> 3, r = t & 7;
+    const int k = (g & 3) * 8 + (g >> 2);
     for (int sweep = 0; sweep < 24; ++sweep) {
         for (int step = 0; step < 63; ++step) {
-            if (t < 32) {
-                int p, q;
-                if (t == 0) {
-                    p = 63, q = step;      // the bye: index 63 does not exist
-                } else {
-                    p = (step + t) % 63, q = (step - t + 63) % 63;
+            const int p = k == 0 ? step : (step + k) % 63;
+            const int q = k == 0 ? 63 : (step - k + 63) % 63;      // k = 0 has the bye: index 63 does not exist
+            double c = 1.0, sn = 0.0;
+            if (p < n && q < n) {
+                const double app = A[p * EJ_LD + p], aqq = A[q * EJ_LD + q], apq = A[p * EJ_LD + q];
+                if (apq * apq > 1.232595164407831e-32 * fabs(app * aqq)) {          // |a_pq| > 2^-53 sqrt(|a_pp a_qq|)
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + tt * tt);
+                    sn = tt * c;
+                    if (r == 0) atomicAdd(n_rot, 1);
+                } else if (apq != 0.0 && r == 0) {
+                    A[p * EJ_LD + q] = 0.0;        // negligible: drop it (both copies) so that it cannot creep back
+                    A[q * EJ_LD + p] = 0.0;
                 }
-                if (p > q) {
-                    const int x = p;
-                    p = q, q = x;
-                }
-                double c = 1.0, sn = 0.0;
-                if (q < n) {
-                    const double app = A[p * EJ_LD + p], aqq = A[q * EJ_LD + q], apq = A[p * EJ_LD + q];
-                    if (apq != 0.0 && fabs(apq) > 1.1102230246251565e-16 * sqrt(fabs(app) * fabs(aqq))) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = 1.0 / sqrt(1.0 + tt * tt);
-                        sn = tt * c;
-                        atomicAdd(n_rot, 1);
-                    } else if (apq != 0.0) {
-                        A[p * EJ_LD + q] = 0.0;    // negligible: drop it (both copies) so that it cannot creep back
-                        A[q * EJ_LD + p] = 0.0;
-                    }
-                }
-                rc[t] = c, rs[t] = sn, rp[t] = p, rq[t] = q;
             }
-            __syncthreads();
-            const double c = rc[k], sn = rs[k];
-            const int p = rp[k], q = rq[k];
             if (sn != 0.0) {   // columns p and q of A and of V:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int i = r + 8 * m;
-                    if (i < n) {
+                    if (i < EJ_N) {                // rows beyond n are zeros and stay zeros
                         const double ap = A[i * EJ_LD + p], aq = A[i * EJ_LD + q];
+                        const double vp = V[i * EJ_LD + p], vq = V[i * EJ_LD + q];
                         A[i * EJ_LD + p] = c * ap - sn * aq;
                         A[i * EJ_LD + q] = sn * ap + c * aq;
-                        const double vp = V[i * EJ_LD + p], vq = V[i * EJ_LD + q];
                         V[i * EJ_LD + p] = c * vp - sn * vq;
                         V[i * EJ_LD + q] = sn * vp + c * vq;
                     }
@@ -203,32 +191,27 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int j = r + 8 * m;
-                    if (j < n) {
+                    if (j < EJ_N) {
                         const double ap = A[p * EJ_LD + j], aq = A[q * EJ_LD + j];
                         A[p * EJ_LD + j] = c * ap - sn * aq;
                         A[q * EJ_LD + j] = sn * ap + c * aq;
                     }
                 }
+                if (r == 0) {  // the rotated pair is diagonal now, exactly (same wave as the stores above: in order)
+                    A[p * EJ_LD + q] = 0.0;
+                    A[q * EJ_LD + p] = 0.0;
+                }
             }
             __syncthreads();
-            if (sn != 0.0 && r == 0) {   // the rotated pair is diagonal now, exactly
-                A[p * EJ_LD + q] = 0.0;
-                A[q * EJ_LD + p] = 0.0;
-            }
-            // (only entries (p, q) / (q, p) are touched here: no pair of the next step reads them before the barrier
-            //  that follows its rotation computation -- every pair meets once per sweep)
         }
-        __syncthreads();
         const int made = *n_rot;
         __syncthreads();
         if (t == 0) *n_rot = 0;
         __syncthreads();                    // the reset lands before the next sweep's first count
         if (made == 0) break;
     }
-    __syncthreads();
 
     // ---- Newton-Schulz: E = (I - V^T V) / 2 into A's storage (eigenvalues saved first), then V += V E ----
-    double *lam = rc;                       // 64 doubles: rc and rs are contiguous
     if (t < NS) lam[t] = t < n ? A[t * EJ_LD + t] : 0.0;
     __syncthreads();
     {
@@ -285,7 +268,7 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
 void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream)
 {
     if (M <= 0) return;
-    const size_t lds = (size_t)(2 * EJ_N * EJ_LD + 64) * sizeof(double) + 65 * sizeof(int);
+    const size_t lds = (size_t)(2 * EJ_N * EJ_LD + NS) * sizeof(double) + sizeof(int);
     hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), lds, stream, S, slot, sqrt_pi, pool, n_states);
 }
 

@@ -144,7 +144,13 @@ def map_genes(fn, genes, workers: int = 8, make_engine=None):
         from .engine import Engine
         import os
         dev = int(os.environ.get("LOCAL_RANK", "0"))
-        make_engine = lambda: Engine(dev)   # noqa: E731
+        def make_engine():
+            e = Engine(dev)
+            if workers > 1 and "CRAB_DEVICE_EIGEN" not in os.environ:
+                # several host threads decomposing ~40 rate matrices per gradient call each contend for the cores, the
+                # GPU has room: kernel 0 takes the decompositions (profiles/r2_scan_timing.txt: 416 -> 259 ms per gene)
+                e.set_eigensolver("device")
+            return e
     pool = queue.Queue()
     engines = [make_engine() for _ in range(workers)]
     for e in engines:
