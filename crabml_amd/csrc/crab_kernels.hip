@@ -26,6 +26,7 @@
 namespace crab {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -91,7 +92,6 @@ __global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__
     // 16-byte stores.  Operand image: registers r, r+1 (r even) of a lane are neighbours there (the (j>>2)&1 bit).
     // Gather image: rows i and i^4 are neighbours (the (i>>2)&1 bit) and live in lanes c and c^4, so each pair of lanes
     // swaps one value per register pair: the lane with bit 2 of c clear stores column j(r), the other column j(r+1).
-    typedef double v2d __attribute__((ext_vector_type(2)));
     const bool hi_half = (c & 4) != 0;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
@@ -118,138 +118,245 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 }
 
 // =============================================================================================
-// kernel 0: batched symmetric eigensolver (parallel cyclic Jacobi in LDS)
+// kernel 0: batched symmetric eigensolver (parallel cyclic Jacobi, matrix and vectors in registers)
 // =============================================================================================
-// One workgroup (256 threads) per matrix.  A (the matrix, overwritten) and V (the accumulated rotations) live in LDS
-// with a row stride of 63 doubles (odd: column walks spread over the banks).  A sweep is 63 steps of 32 disjoint pairs (p, q)
-// (round-robin tournament over 64 indices); a step computes the 32 rotations, applies them to the columns of A and V,
-// then (one barrier later) to the rows of A.  Indices beyond n_states are padding: their rows and columns are exact zeros, their pairs are
-// skipped, so they never mix with the real ones.  Sweeps stop when one passes without a rotation (off-diagonal
-// entries below 2^-53 of the geometric mean of their diagonal entries), at most 24.  Then one Newton-Schulz step
-// V <- V (3 I - V^T V) / 2 (crab_eigen.cpp:reorthogonalise has the reason), and the result is packed for kernel 1.
-constexpr int EJ_N = NS - 1;   // at most 63 states: index 63 is always padding and is not stored
-constexpr int EJ_LD = EJ_N;    // LDS row stride in doubles (odd: column walks spread over the banks); 2 x 31 752 B + tables < 64 KiB
+// One workgroup (256 threads) per matrix.  The 64 indices (n_states real ones, the rest padding with exact zero rows
+// and columns) sit in 64 *seats*: seat k and seat 32 + k (k < 32) form pair k.  A step rotates all 32 pairs at once,
+// A <- J^T A J and V <- V J, then every index but the one in seat 0 moves one seat on along the ring
+// 1, 2, .., 31, 63, 62, .., 32 (the circle method of round-robin tournaments): 63 steps = one sweep let every pair meet
+// once and put every index back into its first seat.
+//   - A in seat order: thread (a, cq) holds rows {a, 32 + a} x columns {4cq .. 4cq+3, 32+4cq .. 32+4cq+3}: four 2 x 2
+//     blocks, each rotated from both sides in registers.  The thread whose patch holds the diagonal block of pair a
+//     computes that pair's rotation and posts (c, s) in a table in LDS.  The move is the only traffic: the patch is
+//     written to LDS at its seats (eight 16-byte stores), and read back from the seats that move into the patch's
+//     (sixteen 8-byte loads at constant offsets).
+//   - V: the same patch of V (rows a and 32 + a, which stay); columns rotate with the patch's four (c, s) and move by
+//     renaming, the four entries that cross to the neighbouring thread by lane shuffles.
+// Two barriers per step.  Sweeps stop when one passes without a rotation (off-diagonal entries below 2^-53 of the
+// geometric mean of their diagonal entries), at most 24.  Then one Newton-Schulz step V <- V (3 I - V^T V) / 2
+// (crab_eigen.cpp:reorthogonalise has the reason), eigenvalues as Rayleigh quotients v^T S v of the corrected
+// vectors (the rotated diagonal carries the rounding of ~500 rotations per index), and the result packed for kernel 1.
+constexpr int EJ_LD = 66;      // LDS row stride in doubles: even (16-byte pieces stay aligned), consecutive rows 16 B apart in the banks
+constexpr size_t EJ_LDS_BYTES = (size_t)(2 * NS * EJ_LD + 64 + NS) * sizeof(double) + 16;
+
+__device__ __forceinline__ int ej_src(int s)                // the seat whose index moves into seat s after a step
+{
+    return s == 0 ? 0 : s == 1 ? 32 : s < 32 ? s - 1 : s < 63 ? s + 1 : 31;
+}
+
+// sqrt(z) and 1 / sqrt(z) for a positive, normal z: the hardware's estimate and two coupled Goldschmidt steps (fma only;
+// ocml's sqrt/rsqrt carry range scaling that the rotation, on the critical path of every step, does not need)
+__device__ __forceinline__ void ej_sqrt_rsqrt(double z, double &root, double &inv_root)
+{
+    const double y = __builtin_amdgcn_rsq(z);
+    double h = z * y, g = 0.5 * y;
+    double r = __builtin_fma(-g, h, 0.5);
+    h = __builtin_fma(h, r, h), g = __builtin_fma(g, r, g);
+    r = __builtin_fma(-g, h, 0.5);
+    h = __builtin_fma(h, r, h), g = __builtin_fma(g, r, g);
+    root = h, inv_root = 2.0 * g;
+}
+
+__device__ __forceinline__ double ej_sel(const double (&x)[4], int m)
+{
+    return m == 0 ? x[0] : m == 1 ? x[1] : m == 2 ? x[2] : x[3];
+}
 
 __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S, const int32_t *__restrict__ slot,
                                                     const double *__restrict__ sqrt_pi, double *__restrict__ pool, int n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *A = reinterpret_cast<double *>(smem_raw);           // [63][EJ_LD]
-    double *V = A + EJ_N * EJ_LD;                               // [63][EJ_LD]
-    double *lam = V + EJ_N * EJ_LD;                             // [64] eigenvalues, once the sweeps are done
+    double *X = reinterpret_cast<double *>(smem_raw);           // [64][EJ_LD] A on the move; scratch of the epilogue
+    double *Vs = X + NS * EJ_LD;                                // [64][EJ_LD] V, once the sweeps are done
+    double *tab = Vs + NS * EJ_LD;                              // [32] (c, s) of the step's rotations
+    double *lam = tab + 64;                                     // [64]
     int *n_rot = reinterpret_cast<int *>(lam + NS);             // rotations made in the current sweep
     const int t = threadIdx.x;
-    const double *Sm = S + (size_t)blockIdx.x * NS * NS;
-    for (int idx = t; idx < EJ_N * EJ_N; idx += 256) {
-        const int i = idx / EJ_N, j = idx - i * EJ_N;
-        A[i * EJ_LD + j] = Sm[i * NS + j];
-        V[i * EJ_LD + j] = i == j ? 1.0 : 0.0;
+    const double *Sm = S + (size_t)blockIdx.x * NS * NS;        // 64 x 64, zero beyond n (the host pads)
+
+    const int a = t >> 3, cq = t & 7;                           // A: pair of rows, eighth of the columns
+    const bool diag = cq == (a >> 2);
+    const int md = a & 3;                                       // where the diagonal block sits in the patch
+    double xtt[4], xtb[4], xbt[4], xbb[4];                      // A: rows {a, 32 + a} x seats {4cq + m, 32 + 4cq + m}
+    double vtt[4], vtb[4], vbt[4], vbb[4];                      // V: the same patch (its rows do not move)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        xtt[m] = Sm[a * NS + 4 * cq + m], xtb[m] = Sm[a * NS + 32 + 4 * cq + m];
+        xbt[m] = Sm[(32 + a) * NS + 4 * cq + m], xbb[m] = Sm[(32 + a) * NS + 32 + 4 * cq + m];
     }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        vtt[m] = a == 4 * cq + m ? 1.0 : 0.0, vtb[m] = 0.0;
+        vbt[m] = 0.0, vbb[m] = a == 4 * cq + m ? 1.0 : 0.0;
+    }
+    const int rt = ej_src(a) * EJ_LD, rb = ej_src(32 + a) * EJ_LD;   // where the patch's next contents are, after a store at the seats
+    int ct[4], cb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ct[m] = ej_src(4 * cq + m), cb[m] = ej_src(32 + 4 * cq + m);
     if (t == 0) *n_rot = 0;
     __syncthreads();
 
-    // Thread t works for pair k on rows / columns r, r + 8, ...  The four pairs of a half-wave are 8 apart, so that
-    // their columns (row stride 63 = -1 mod 32 bank pairs) fall into different banks.  The 8 threads of a pair sit in
-    // one wave and each computes the pair's rotation itself: no table, no barrier before the column update (a pair's
-    // threads read a_pp, a_qq, a_pq in lockstep before any of them writes, and no other pair touches columns p, q).
-    const int g = t >> 3, r = t & 7;
-    const int k = (g & 3) * 8 + (g >> 2);
+#ifdef EJ_PROF
+    long long pf[6] = {0, 0, 0, 0, 0, 0}, pf_t = clock64();
+    int pf_sweeps = 0;
+#define EJ_MARK(i) { const long long now_ = clock64(); pf[i] += now_ - pf_t; pf_t = now_; }
+#else
+#define EJ_MARK(i)
+#endif
     for (int sweep = 0; sweep < 24; ++sweep) {
+        int made_here = 0;
+#ifdef EJ_PROF
+        ++pf_sweeps;
+#endif
         for (int step = 0; step < 63; ++step) {
-            const int p = k == 0 ? step : (step + k) % 63;
-            const int q = k == 0 ? 63 : (step - k + 63) % 63;      // k = 0 has the bye: index 63 does not exist
-            double c = 1.0, sn = 0.0;
-            if (p < n && q < n) {
-                const double app = A[p * EJ_LD + p], aqq = A[q * EJ_LD + q], apq = A[p * EJ_LD + q];
+            EJ_MARK(5)
+            bool clear = false;                                 // the pair's off-diagonal entries become exact zeros
+            if (diag) {
+                double c = 1.0, sn = 0.0;
+                // (a pair with a padding index has a_pq = 0 exactly and is left alone)
+                const double app = ej_sel(xtt, md), aqq = ej_sel(xbb, md), apq = ej_sel(xtb, md);
                 if (apq * apq > 1.232595164407831e-32 * fabs(app * aqq)) {          // |a_pq| > 2^-53 sqrt(|a_pp a_qq|)
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + tt * tt);
-                    sn = tt * c;
-                    if (r == 0) atomicAdd(n_rot, 1);
-                } else if (apq != 0.0 && r == 0) {
-                    A[p * EJ_LD + q] = 0.0;        // negligible: drop it (both copies) so that it cannot creep back
-                    A[q * EJ_LD + p] = 0.0;
+                    // t = sign(d) b / (|d| + sqrt(d^2 + b^2)) with d = a_qq - a_pp, b = 2 a_pq; c = 1 / sqrt(1 + t^2), s = t c
+                    const double d = aqq - app, b2 = 2.0 * apq;
+                    double root, inv;
+                    ej_sqrt_rsqrt(d * d + b2 * b2, root, inv);
+                    const double big = fabs(d) + root;
+                    ej_sqrt_rsqrt(big * big + b2 * b2, root, inv);
+                    c = big * inv;
+                    sn = (d >= 0.0 ? b2 : -b2) * inv;
+                    ++made_here;
+                    clear = true;
+                } else if (apq != 0.0) {
+                    clear = true;                               // negligible: drop it (both copies) so that it cannot creep back
                 }
+                *reinterpret_cast<v2d *>(tab + 2 * a) = (v2d){c, sn};
             }
-            if (sn != 0.0) {   // columns p and q of A and of V:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int i = r + 8 * m;
-                    if (i < EJ_N) {                // rows beyond n are zeros and stay zeros
-                        const double ap = A[i * EJ_LD + p], aq = A[i * EJ_LD + q];
-                        const double vp = V[i * EJ_LD + p], vq = V[i * EJ_LD + q];
-                        A[i * EJ_LD + p] = c * ap - sn * aq;
-                        A[i * EJ_LD + q] = sn * ap + c * aq;
-                        V[i * EJ_LD + p] = c * vp - sn * vq;
-                        V[i * EJ_LD + q] = sn * vp + c * vq;
-                    }
-                }
-            }
+            EJ_MARK(0)
             __syncthreads();
-            if (sn != 0.0) {   // rows p and q of A
+            EJ_MARK(1)
+            {
+                const v2d ra = *reinterpret_cast<const v2d *>(tab + 2 * a);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int j = r + 8 * m;
-                    if (j < EJ_N) {
-                        const double ap = A[p * EJ_LD + j], aq = A[q * EJ_LD + j];
-                        A[p * EJ_LD + j] = c * ap - sn * aq;
-                        A[q * EJ_LD + j] = sn * ap + c * aq;
-                    }
+                for (int m = 0; m < 4; ++m) {
+                    const v2d rc = *reinterpret_cast<const v2d *>(tab + 2 * (4 * cq + m));
+                    // columns:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q);  then rows, the same way
+                    const double tt = rc.x * xtt[m] - rc.y * xtb[m], tb = rc.y * xtt[m] + rc.x * xtb[m];
+                    const double bt = rc.x * xbt[m] - rc.y * xbb[m], bb = rc.y * xbt[m] + rc.x * xbb[m];
+                    xtt[m] = ra.x * tt - ra.y * bt, xbt[m] = ra.y * tt + ra.x * bt;
+                    xtb[m] = ra.x * tb - ra.y * bb, xbb[m] = ra.y * tb + ra.x * bb;
+                    if (clear && m == md) xtb[m] = 0.0, xbt[m] = 0.0;
+                    const double v0 = rc.x * vtt[m] - rc.y * vtb[m], v1 = rc.y * vtt[m] + rc.x * vtb[m];
+                    const double v2 = rc.x * vbt[m] - rc.y * vbb[m], v3 = rc.y * vbt[m] + rc.x * vbb[m];
+                    vtt[m] = v0, vtb[m] = v1, vbt[m] = v2, vbb[m] = v3;
                 }
-                if (r == 0) {  // the rotated pair is diagonal now, exactly (same wave as the stores above: in order)
-                    A[p * EJ_LD + q] = 0.0;
-                    A[q * EJ_LD + p] = 0.0;
-                }
+                double *row_t = X + a * EJ_LD + 4 * cq, *row_b = X + (32 + a) * EJ_LD + 4 * cq;
+                *reinterpret_cast<v2d *>(row_t) = (v2d){xtt[0], xtt[1]};
+                *reinterpret_cast<v2d *>(row_t + 2) = (v2d){xtt[2], xtt[3]};
+                *reinterpret_cast<v2d *>(row_t + 32) = (v2d){xtb[0], xtb[1]};
+                *reinterpret_cast<v2d *>(row_t + 34) = (v2d){xtb[2], xtb[3]};
+                *reinterpret_cast<v2d *>(row_b) = (v2d){xbt[0], xbt[1]};
+                *reinterpret_cast<v2d *>(row_b + 2) = (v2d){xbt[2], xbt[3]};
+                *reinterpret_cast<v2d *>(row_b + 32) = (v2d){xbb[0], xbb[1]};
+                *reinterpret_cast<v2d *>(row_b + 34) = (v2d){xbb[2], xbb[3]};
             }
+            EJ_MARK(2)
             __syncthreads();
+            EJ_MARK(3)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                xtt[m] = X[rt + ct[m]], xtb[m] = X[rt + cb[m]];
+                xbt[m] = X[rb + ct[m]], xbb[m] = X[rb + cb[m]];
+            }
+            {   // V's columns move with their indices: seat s takes the column of seat ej_src(s); neighbours are one lane away
+                const double lt = __shfl_up(vtt[3], 1), lb = __shfl_up(vbt[3], 1);
+                const double rt_ = __shfl_down(vtb[0], 1), rb_ = __shfl_down(vbb[0], 1);
+                const double t0 = vtt[0], t3 = vtt[3], b0 = vbt[0], b3 = vbt[3], tb0 = vtb[0], bb0 = vbb[0];
+#pragma unroll
+                for (int m = 3; m >= 1; --m) vtt[m] = vtt[m - 1], vbt[m] = vbt[m - 1];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) vtb[m] = vtb[m + 1], vbb[m] = vbb[m + 1];
+                vtt[0] = lt, vbt[0] = lb, vtb[3] = rt_, vbb[3] = rb_;
+                if (cq == 0) vtt[0] = t0, vbt[0] = b0, vtt[1] = tb0, vbt[1] = bb0;   // seat 0 keeps its index, seat 1 takes seat 32's
+                if (cq == 7) vtb[3] = t3, vbb[3] = b3;                               // seat 63 takes seat 31's
+            }
+            EJ_MARK(4)
         }
+        if (made_here) atomicAdd(n_rot, made_here);
+        __syncthreads();
         const int made = *n_rot;
         __syncthreads();
-        if (t == 0) *n_rot = 0;
-        __syncthreads();                    // the reset lands before the next sweep's first count
+        if (t == 0) *n_rot = 0;                                 // (the next count is 126 barriers away)
         if (made == 0) break;
     }
-
-    // ---- Newton-Schulz: E = (I - V^T V) / 2 into A's storage (eigenvalues saved first), then V += V E ----
-    if (t < NS) lam[t] = t < n ? A[t * EJ_LD + t] : 0.0;
+#ifdef EJ_PROF
+    if (blockIdx.x == 0 && (t == 0 || t == 255 || t == 9))
+        printf("eigen_kernel t=%d sweeps %d; cycles: rotation %lld, barrier %lld, rotate+store %lld, barrier %lld, load+shuffle %lld, loop %lld\n", t,
+               pf_sweeps, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5]);
+    pf_t = clock64();
+#endif
+    // every index is back in its first seat: seat s = matrix index s
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        Vs[a * EJ_LD + 4 * cq + m] = vtt[m], Vs[a * EJ_LD + 32 + 4 * cq + m] = vtb[m];
+        Vs[(32 + a) * EJ_LD + 4 * cq + m] = vbt[m], Vs[(32 + a) * EJ_LD + 32 + 4 * cq + m] = vbb[m];
+    }
     __syncthreads();
+
+    // ---- Newton-Schulz: E = (I - V^T V) / 2 into X, then V += V E ----
+    const int row = t >> 2, l0 = (t & 3) * 16;                  // 16 entries of one row of a 64 x 64 product
     {
-        const int kk = t >> 2, l0 = (t & 3) * 16;    // 16 entries of row kk of G = V^T V
         double g[16];
 #pragma unroll
         for (int x = 0; x < 16; ++x) g[x] = 0.0;
-        if (kk < n)
+        if (row < n)
             for (int i = 0; i < n; ++i) {
-                const double vk = V[i * EJ_LD + kk];
+                const double vk = Vs[i * EJ_LD + row];
 #pragma unroll
-                for (int x = 0; x < 16; ++x)
-                    if (l0 + x < EJ_N) g[x] += vk * V[i * EJ_LD + l0 + x];
+                for (int x = 0; x < 16; ++x) g[x] += vk * Vs[i * EJ_LD + l0 + x];
             }
-        __syncthreads();
-        if (kk < EJ_N)
 #pragma unroll
-            for (int x = 0; x < 16; ++x)
-                if (l0 + x < EJ_N) A[kk * EJ_LD + l0 + x] = (kk < n && l0 + x < n) ? 0.5 * ((kk == l0 + x ? 1.0 : 0.0) - g[x]) : 0.0;
+        for (int x = 0; x < 16; ++x)
+            X[row * EJ_LD + l0 + x] = (row < n && l0 + x < n) ? 0.5 * ((row == l0 + x ? 1.0 : 0.0) - g[x]) : 0.0;
     }
     __syncthreads();
     {
-        const int i = t >> 2, l0 = (t & 3) * 16;     // 16 entries of row i of V E
         double w[16];
 #pragma unroll
         for (int x = 0; x < 16; ++x) w[x] = 0.0;
-        if (i < n)
+        if (row < n)
             for (int kk = 0; kk < n; ++kk) {
-                const double vik = V[i * EJ_LD + kk];
+                const double vik = Vs[row * EJ_LD + kk];
 #pragma unroll
-                for (int x = 0; x < 16; ++x)
-                    if (l0 + x < EJ_N) w[x] += vik * A[kk * EJ_LD + l0 + x];
+                for (int x = 0; x < 16; ++x) w[x] += vik * X[kk * EJ_LD + l0 + x];
             }
-        __syncthreads();                    // all reads of V done before anybody updates it
-        if (i < n)
+        __syncthreads();                    // all reads of V and E done before anybody updates V or overwrites E
+        if (row < n)
 #pragma unroll
             for (int x = 0; x < 16; ++x)
-                if (l0 + x < n) V[i * EJ_LD + l0 + x] += w[x];
+                if (l0 + x < n) Vs[row * EJ_LD + l0 + x] += w[x];
+    }
+    // ---- eigenvalues: lambda_l = sum_i V[i][l] (S V)[i][l] ----
+    for (int idx = t; idx < NS * NS; idx += 256) X[(idx >> 6) * EJ_LD + (idx & 63)] = Sm[idx];
+    __syncthreads();
+    {
+        double w[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) w[x] = 0.0;
+        if (row < n)
+            for (int kk = 0; kk < n; ++kk) {
+                const double sik = X[row * EJ_LD + kk];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) w[x] += sik * Vs[kk * EJ_LD + l0 + x];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 16; ++x) X[row * EJ_LD + l0 + x] = row < n ? w[x] * Vs[row * EJ_LD + l0 + x] : 0.0;
+    }
+    __syncthreads();
+    if (t < NS) {
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) sum += X[i * EJ_LD + t];
+        lam[t] = t < n ? sum : 0.0;
     }
     __syncthreads();
 
@@ -258,18 +365,23 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
     for (int idx = t; idx < NS * NS; idx += 256) {
         const int kk = idx >> 6, i = idx & 63;
         const bool real = kk < n && i < n;
-        const double v = real ? V[i * EJ_LD + kk] : 0.0, sq = real ? sqrt_pi[i] : 1.0;
+        const double v = real ? Vs[i * EJ_LD + kk] : 0.0, sq = real ? sqrt_pi[i] : 1.0;
         out[EIG_UT + idx] = real ? v / sq : 0.0;
         out[EIG_UINV + idx] = real ? v * sq : 0.0;
     }
     if (t < NS) out[EIG_LAM + t] = lam[t];
+#ifdef EJ_PROF
+    if (blockIdx.x == 0 && t == 0) printf("eigen_kernel epilogue %lld cycles\n", clock64() - pf_t);
+#endif
 }
 
 void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream)
 {
     if (M <= 0) return;
-    const size_t lds = (size_t)(2 * EJ_N * EJ_LD + NS) * sizeof(double) + sizeof(int);
-    hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), lds, stream, S, slot, sqrt_pi, pool, n_states);
+    // more than the 64 KiB a kernel gets without asking (per device: the attribute belongs to the loaded code object);
+    // if this fails the launch does too, and the engine reports that
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eigen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EJ_LDS_BYTES);
+    hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), EJ_LDS_BYTES, stream, S, slot, sqrt_pi, pool, n_states);
 }
 
 // =============================================================================================
@@ -318,7 +430,6 @@ struct Plan {
     static_assert(TOP <= 256, "register plan exceeds the two-waves-per-SIMD budget");
 };
 
-typedef double v2d __attribute__((ext_vector_type(2)));
 
 // ---- one-instruction building blocks (register numbers are template arguments) ----
 template <int D, int A, int B, bool FIRST>
