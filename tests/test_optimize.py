@@ -407,6 +407,7 @@ def test_gene_scan_on_the_device():
         warnings.simplefilter("ignore")                               # a negative statistic on 60 codons only warns
         rows = scan.scan(genes, null="M7", workers=2)
         with Engine(0) as eng:
+            eng.set_eigensolver("device")                             # what scan's engines use when they share the card
             alone = [scan.lrt_gene(eng, a, t, null="M7") for a, t in genes]
         mixture = scan.scan(genes[:1], null="M8a", workers=1)
     for r, a in zip(rows, alone):
