@@ -76,8 +76,9 @@ int crab_create(int device, crab_engine **out);
 int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
 /* Where CachedQMatrix::new (matrix.rs:31-75) runs.  0 (default): on the host, one task per matrix (0.25 ms for the 11
  * matrices of an M8 evaluation: the shortest latency when few matrices change per call).  1: on the device, one
- * workgroup per matrix (parallel cyclic Jacobi in LDS + one re-orthogonalisation step; no host work beyond symmetrising
- * the matrix, no synchronisation): for callers that change many rate matrices per call -- free-ratio fits (1 998 per
+ * workgroup per matrix (parallel cyclic Jacobi in registers + one re-orthogonalisation step, eigenvalues as Rayleigh
+ * quotients; no host work beyond symmetrising the matrix, no synchronisation; 0.7-0.9 ms whatever the number of matrices
+ * up to one per CU): for callers that change many rate matrices per call -- free-ratio fits (1 998 per
  * kappa row at 1000 taxa), gene scans with several engines per GPU (43 per gradient call each).  Results of the two
  * solvers agree to the accuracy of either (P entries within 2e-14); within one setting batched and single evaluations
  * stay bit-identical.  The environment variable CRAB_DEVICE_EIGEN=1 sets the default of new engines. */
