@@ -2897,40 +2897,69 @@ struct CacheKey {  // contents, not addresses: callers may re-pack the same alig
     int n_leaves;
     int64_t n_sites;
     int n_states;
-    uint64_t data_hash, tree_hash;
+    uint64_t data_hash[2];                       // 128 bits over the codes (the tree is compared entry by entry)
+    std::vector<int32_t> parents, node_ids, leaf_ids;
     bool operator==(const CacheKey &o) const
     {
         return device == o.device && n_leaves == o.n_leaves && n_sites == o.n_sites && n_states == o.n_states &&
-               data_hash == o.data_hash && tree_hash == o.tree_hash;
+               data_hash[0] == o.data_hash[0] && data_hash[1] == o.data_hash[1] && parents == o.parents &&
+               node_ids == o.node_ids && leaf_ids == o.leaf_ids;
     }
 };
 
 struct CacheEntry {
     CacheKey key;
-    crab_engine *engine;
+    crab_engine *engine = nullptr;
+    std::mutex busy;                             // one evaluation at a time per engine; other entries run alongside
+    ~CacheEntry()
+    {
+        if (engine) crab_destroy(engine);        // runs when the last user lets go: eviction never pulls an engine from under a call
+    }
 };
 
-std::mutex g_cache_mutex;
-std::list<CacheEntry> g_cache;  // most recent first
+std::mutex g_cache_mutex;                        // guards the list only, never held across an evaluation
+// most recent first; never destroyed: at process exit the HIP runtime may already be gone, so engines still cached then are
+// left to the operating system (crab_clear_cache releases them in an orderly way)
+std::list<std::shared_ptr<CacheEntry>> &g_cache = *new std::list<std::shared_ptr<CacheEntry>>;
 constexpr size_t CACHE_MAX = 8;
 
 }  // namespace
-uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
+static void hash_lanes(const void *p, size_t bytes, uint64_t seed, uint64_t h[4], size_t *tail_from)
 {
     const unsigned char *b = (const unsigned char *)p;
-    uint64_t h0 = seed, h1 = seed ^ 0x9e3779b97f4a7c15ull, h2 = seed + 0x632be59bd9b4e019ull, h3 = ~seed;
+    h[0] = seed, h[1] = seed ^ 0x9e3779b97f4a7c15ull, h[2] = seed + 0x632be59bd9b4e019ull, h[3] = ~seed;
     size_t i = 0;
     for (; i + 32 <= bytes; i += 32) {
         uint64_t w[4];
         std::memcpy(w, b + i, 32);
-        h0 = (h0 ^ w[0]) * 0x9fb21c651e98df25ull; h0 ^= h0 >> 29;
-        h1 = (h1 ^ w[1]) * 0xd6e8feb86659fd93ull; h1 ^= h1 >> 31;
-        h2 = (h2 ^ w[2]) * 0xc2b2ae3d27d4eb4full; h2 ^= h2 >> 27;
-        h3 = (h3 ^ w[3]) * 0x165667b19e3779f9ull; h3 ^= h3 >> 33;
+        h[0] = (h[0] ^ w[0]) * 0x9fb21c651e98df25ull; h[0] ^= h[0] >> 29;
+        h[1] = (h[1] ^ w[1]) * 0xd6e8feb86659fd93ull; h[1] ^= h[1] >> 31;
+        h[2] = (h[2] ^ w[2]) * 0xc2b2ae3d27d4eb4full; h[2] ^= h[2] >> 27;
+        h[3] = (h[3] ^ w[3]) * 0x165667b19e3779f9ull; h[3] ^= h[3] >> 33;
     }
-    uint64_t h = mix64(mix64(h0, h1), mix64(h2, h3));
-    for (; i < bytes; ++i) h = mix64(h, b[i]);
+    *tail_from = i;
+}
+
+uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
+{
+    uint64_t l[4];
+    size_t i;
+    hash_lanes(p, bytes, seed, l, &i);
+    uint64_t h = mix64(mix64(l[0], l[1]), mix64(l[2], l[3]));
+    for (const unsigned char *b = (const unsigned char *)p; i < bytes; ++i) h = mix64(h, b[i]);
     return mix64(h, bytes);
+}
+
+// two 64-bit digests of the same pass (the second folds the four lanes in another order with other constants)
+static void hash_words2(const void *p, size_t bytes, uint64_t seed, uint64_t out[2])
+{
+    uint64_t l[4];
+    size_t i;
+    hash_lanes(p, bytes, seed, l, &i);
+    uint64_t h = mix64(mix64(l[0], l[1]), mix64(l[2], l[3]));
+    uint64_t g = mix64(mix64(l[3] + 0x2545f4914f6cdd1dull, l[1]), mix64(l[0] ^ 0xff51afd7ed558ccdull, l[2]));
+    for (const unsigned char *b = (const unsigned char *)p; i < bytes; ++i) h = mix64(h, b[i]), g = mix64(g ^ 0x5bd1e995, b[i]);
+    out[0] = mix64(h, bytes), out[1] = mix64(g, ~(uint64_t)bytes);
 }
 namespace {
 
@@ -2954,9 +2983,10 @@ std::vector<int> devices_from_env()
     return out;
 }
 
-// Returns a cached engine for this (alignment, tree), creating it on first sight.  The caller holds g_cache_mutex.
-crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents,
-                           const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_ids, int *status)
+// Returns the cache entry for this (alignment, tree), creating engine and entry on first sight.  Hashing happens before
+// the list lock is taken; a new engine is built under it (rare: once per alignment).
+std::shared_ptr<CacheEntry> cached_engine(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents,
+                                          const int32_t *codes, int n_leaves, int64_t n_sites, const int32_t *leaf_ids, int *status)
 {
     *status = CRAB_OK;
     if (!codes || !parents || n_nodes < 1 || n_leaves < 1 || n_sites < 0) {
@@ -2969,31 +2999,31 @@ crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t 
         devs = devices_from_env();
         device = -1 - (int)(hash_words(devs.data(), devs.size() * sizeof(int), 5) & 0x3fffffff);   // one key per device list
     }
-    CacheKey key{device, n_leaves, n_sites, n_states, 0, 0};
+    CacheKey key{device, n_leaves, n_sites, n_states, {0, 0}, {}, {}, {}};
+    key.parents.assign(parents, parents + n_nodes);
+    if (node_ids) key.node_ids.assign(node_ids, node_ids + n_nodes);
+    if (leaf_ids) key.leaf_ids.assign(leaf_ids, leaf_ids + n_leaves);
     // the stateless boundary hands the alignment over on every call (4 MB at C2): hash it in 256 KiB chunks on the
     // host pool, then hash the chunk hashes
     {
         const size_t bytes = (size_t)n_leaves * n_sites * sizeof(int32_t), chunk = 256 * 1024;
         const int n_chunks = (int)((bytes + chunk - 1) / chunk);
         if (n_chunks <= 1) {
-            key.data_hash = hash_words(codes, bytes, 1);
+            hash_words2(codes, bytes, 1, key.data_hash);
         } else {
-            std::vector<uint64_t> part(n_chunks);
+            std::vector<uint64_t> part(2 * (size_t)n_chunks);
             parallel_for(n_chunks, [&](int i) {
                 const size_t lo = (size_t)i * chunk;
-                part[i] = hash_words((const char *)codes + lo, std::min(chunk, bytes - lo), 1 + (uint64_t)i);
+                hash_words2((const char *)codes + lo, std::min(chunk, bytes - lo), 1 + (uint64_t)i, &part[2 * (size_t)i]);
             });
-            key.data_hash = hash_words(part.data(), part.size() * sizeof(uint64_t), bytes);
+            hash_words2(part.data(), part.size() * sizeof(uint64_t), bytes, key.data_hash);
         }
     }
-    uint64_t th = hash_words(parents, (size_t)n_nodes * sizeof(int32_t), 2);
-    if (node_ids) th = mix64(th, hash_words(node_ids, (size_t)n_nodes * sizeof(int32_t), 3));
-    if (leaf_ids) th = mix64(th, hash_words(leaf_ids, (size_t)n_leaves * sizeof(int32_t), 4));
-    key.tree_hash = th;
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
     for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
-        if (it->key == key) {
+        if ((*it)->key == key) {
             g_cache.splice(g_cache.begin(), g_cache, it);
-            return g_cache.front().engine;
+            return g_cache.front();
         }
     crab_engine *e = nullptr;
     int rc = devs.size() > 1 ? crab_create_multi(devs.data(), (int)devs.size(), &e) : crab_create(devs.empty() ? device : devs[0], &e);
@@ -3008,24 +3038,24 @@ crab_engine *cached_engine(int device, int n_states, int n_nodes, const int32_t 
     }
     *status = rc;
     if (!e) return nullptr;
-    g_cache.push_front({key, e});
-    while (g_cache.size() > CACHE_MAX) {
-        crab_destroy(g_cache.back().engine);
-        g_cache.pop_back();
-    }
-    return e;
+    auto entry = std::make_shared<CacheEntry>();
+    entry->key = std::move(key);
+    entry->engine = e;
+    g_cache.push_front(entry);
+    while (g_cache.size() > CACHE_MAX) g_cache.pop_back();   // an evicted engine lives until its current call returns
+    return entry;
 }
 
 template <typename F>
 int with_cached(int device, int n_states, int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *codes,
                 int n_leaves, int64_t n_sites, const int32_t *leaf_ids, F &&call)
 {
-    std::lock_guard<std::mutex> lk(g_cache_mutex);
     int status = CRAB_OK;
-    crab_engine *e = cached_engine(device, n_states, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_ids, &status);
-    if (!e) return status;
-    const int rc = call(e);
-    if (rc != CRAB_OK) g_last_error = e->err;
+    std::shared_ptr<CacheEntry> entry = cached_engine(device, n_states, n_nodes, node_ids, parents, codes, n_leaves, n_sites, leaf_ids, &status);
+    if (!entry) return status;
+    std::lock_guard<std::mutex> lk(entry->busy);
+    const int rc = call(entry->engine);
+    if (rc != CRAB_OK) g_last_error = entry->engine->err;
     return rc;
 }
 
@@ -3096,8 +3126,7 @@ int crab_compute_log_likelihood_branch(int device, int n, const int32_t *codes, 
 void crab_clear_cache(void)
 {
     std::lock_guard<std::mutex> lk(g_cache_mutex);
-    for (auto &c : g_cache) crab_destroy(c.engine);
-    g_cache.clear();
+    g_cache.clear();                             // engines still inside a call are destroyed when it returns
 }
 
 }  // extern "C"

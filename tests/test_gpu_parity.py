@@ -236,6 +236,47 @@ def test_shim_functions_match_the_handle_api(gpu_engine_cls, oracle):
     shim.clear_cache()
 
 
+def test_one_shot_callers_in_parallel_and_cache_turnover(gpu_engine_cls):
+    """The handle cache behind the seven stateless functions: threads working on different alignments run side by side
+    (the list lock is not held across an evaluation), twelve alignments turn the eight-entry cache over while calls are
+    in flight, alignments that differ in one codon or one parent index are different entries, and every value equals
+    the one a fresh engine gives."""
+    from concurrent.futures import ThreadPoolExecutor
+    from crabml_amd import crabml_rust as shim
+    c = load_case("lysozyme_m8")
+    ts, leaf = tree_structure(c["parent"]), leaf_ids(c)
+    bl, names = c["branch_lengths"].tolist(), [str(x) for x in c["leaf_names"]]
+    rng = np.random.default_rng(8)
+    aligns = []
+    for i in range(12):
+        seq = c["sequences"].copy()
+        if i:
+            seq[rng.integers(0, seq.shape[0]), rng.integers(0, seq.shape[1])] = int(rng.integers(0, 61))   # one codon differs
+        aligns.append(np.ascontiguousarray(seq))
+    want = []
+    for seq in aligns:
+        with _engine(gpu_engine_cls, c["parent"], seq) as eng:
+            want.append(eng.site_classes(c["Q"], c["proportions"], c["pi"], c["branch_lengths"]))
+    assert len(set(want)) > 6
+
+    def call(i):
+        return shim.compute_site_class_log_likelihood(list(c["Q"]), list(c["proportions"]), c["pi"], ts, bl, names, aligns[i % 12], leaf)
+
+    shim.clear_cache()
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        got = list(ex.map(call, range(72)))
+    assert got == [want[i % 12] for i in range(72)]
+    # the same codes on a tree with two leaves exchanged under their parents: another entry, another value
+    par = c["parent"].copy()
+    kids = [i for i in range(len(par)) if par[i] != par[0] and i < len(leaf)]
+    par[0], par[kids[0]] = par[kids[0]], par[0]
+    swapped = shim.compute_site_class_log_likelihood(list(c["Q"]), list(c["proportions"]), c["pi"], tree_structure(par), bl, names, aligns[0], leaf)
+    with _engine(gpu_engine_cls, par, aligns[0]) as eng:
+        assert swapped == eng.site_classes(c["Q"], c["proportions"], c["pi"], c["branch_lengths"])
+    assert call(0) == want[0]
+    shim.clear_cache()
+
+
 def test_matrix_exponential_on_device(gpu_engine_cls, oracle):
     from scipy.linalg import expm
     from crabml_amd import crabml_rust as shim
