@@ -114,6 +114,27 @@ def test_other_state_spaces_batches_and_partial_updates(gpu_engine_cls, oracle):
     assert np.abs(got - host).max() < TOTAL_ATOL
 
 
+def test_multi_device_handle_with_the_device_eigensolver(gpu_engine_cls):
+    """Every shard decomposes on its own device: same bits from each (one kernel, one input), so the shard-ordered sum
+    equals the single engine's to the slice tolerance and repeats bit for bit."""
+    from crabml_amd import synth
+    case = synth.make_case("M8", 24, 900, seed=12)
+    with _engine(gpu_engine_cls, case.parent, case.codes, "device") as one:
+        want = one.codon_site_classes(case.kappa, case.class_omegas, case.proportions, case.pi, case.branch_lengths)
+        _, want_sites = one.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths, return_sites=True)
+    eng = gpu_engine_cls([0, 0, 0])
+    try:
+        eng.set_eigensolver("device")
+        eng.set_tree(case.parent, np.arange(case.codes.shape[0]))
+        eng.set_alignment(case.codes)
+        got = eng.codon_site_classes(case.kappa, case.class_omegas, case.proportions, case.pi, case.branch_lengths)
+        _, sites = eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths, return_sites=True)
+        again = eng.codon_site_classes(case.kappa, case.class_omegas, case.proportions, case.pi, case.branch_lengths)
+    finally:
+        eng.close()
+    assert again == got and abs(got - want) < 1e-7 and np.array_equal(sites, want_sites)
+
+
 def test_many_matrices_per_call(gpu_engine_cls):
     """Free-ratio at 1000 taxa: a kappa change decomposes 1 998 matrices.  Same likelihood from both solvers; timing printed."""
     from crabml_amd import synth
