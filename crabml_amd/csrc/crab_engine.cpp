@@ -463,6 +463,8 @@ struct crab_engine : TreeProgram {
     DevBuf<double> d_beb_F, d_beb_props, d_beb_lnfx, d_beb_w, d_beb_post;
     PinBuf<double> h_eig, h_small, h_out, h_S;
     DevBuf<double> d_S;
+    DevBuf<int32_t> d_eig_status;   // kernel 0's convergence flag
+    PinBuf<int32_t> h_eig_status;
     bool device_eigen = false;   // decompose on the device (kernel 0) instead of on the host: crab_set_eigensolver
 
     EigPool eig_pool;
@@ -1594,7 +1596,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
 
     // ---- device ----
     HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
-    if (device_eigen) launch_eigen(d_eig_S, d_eig_slots, d_eig_sqrt_pi, pool.d, (int)todo.size(), n, e->stream);
+    if (device_eigen) {
+        e->d_eig_status.ensure(1);
+        e->h_eig_status.ensure(1);
+        HIP_CHECK(hipMemsetAsync(e->d_eig_status.p, 0, sizeof(int32_t), e->stream));
+        launch_eigen(d_eig_S, d_eig_slots, d_eig_sqrt_pi, pool.d, (int)todo.size(), n, e->d_eig_status.p, e->stream);
+        HIP_CHECK(hipMemcpyAsync(e->h_eig_status.p, e->d_eig_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    }
     launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, M, n, true, e->stream);
 
     PruneArgs pa{};
@@ -1742,6 +1750,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     HIP_CHECK(hipStreamSynchronize(e->stream));
     HIP_CHECK(hipGetLastError());
+    if (device_eigen && e->h_eig_status.p[0] != 0) {   // forget what kernel 0 left in the new slots
+        for (int sl : new_slots) pool.drop(sl);
+        fail(CRAB_ERR_EIGEN, "Eigendecomposition failed: the device solver did not converge in 24 sweeps");
+    }
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev_begin, e->ev_end));
     e->last_device_ms = ms;

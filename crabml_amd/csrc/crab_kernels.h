@@ -116,7 +116,8 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 // For m in [0, M): S + m*NS*NS is the symmetrised rate matrix Pi^1/2 Q Pi^-1/2, padded with zeros to 64 x 64; the packed
 // eigensystem (crab_eigen.h layout: U^T, U^-1, lambda) is written to pool + slot[m]*EIG_STRIDE.  One workgroup per
 // matrix: parallel cyclic Jacobi in LDS, then one Newton-Schulz step on the eigenvectors.  sqrt_pi: [64], zero beyond n.
-void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream);
+void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, int *status,
+                  hipStream_t stream);   // *status (zeroed by the caller) gets bit 0 set if a matrix did not converge
 
 // ---- kernel 2: Felsenstein pruning, whole tree per (pattern tile, class)  ---------------------
 // (replaces likelihood.rs:120-132,176-246 and branch_site_likelihood.rs:222-299)

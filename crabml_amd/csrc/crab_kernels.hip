@@ -163,7 +163,8 @@ __device__ __forceinline__ double ej_sel(const double (&x)[4], int m)
 }
 
 __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S, const int32_t *__restrict__ slot,
-                                                    const double *__restrict__ sqrt_pi, double *__restrict__ pool, int n)
+                                                    const double *__restrict__ sqrt_pi, double *__restrict__ pool, int n,
+                                                    int max_sweeps, int *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *X = reinterpret_cast<double *>(smem_raw);           // [64][EJ_LD] A on the move; scratch of the epilogue
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
 #else
 #define EJ_MARK(i)
 #endif
-    for (int sweep = 0; sweep < 24; ++sweep) {
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         int made_here = 0;
 #ifdef EJ_PROF
         ++pf_sweeps;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
         __syncthreads();
         if (t == 0) *n_rot = 0;                                 // (the next count is 126 barriers away)
         if (made == 0) break;
+        if (sweep == max_sweeps - 1 && t == 0) atomicOr(status, 1);   // still rotating after the last sweep: the engine fails the call
     }
 #ifdef EJ_PROF
     if (blockIdx.x == 0 && (t == 0 || t == 255 || t == 9))
@@ -375,13 +377,20 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
 #endif
 }
 
-void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, hipStream_t stream)
+void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, double *pool, int M, int n_states, int *status,
+                  hipStream_t stream)
 {
     if (M <= 0) return;
     // more than the 64 KiB a kernel gets without asking (per device: the attribute belongs to the loaded code object);
     // if this fails the launch does too, and the engine reports that
+    // 24 sweeps are far more than a symmetric matrix needs (9-10 at n = 61); CRAB_EIGEN_MAX_SWEEPS exists for the test of the failure path
+    static const int max_sweeps = [] {
+        const char *sv = std::getenv("CRAB_EIGEN_MAX_SWEEPS");
+        const int v = sv ? std::atoi(sv) : 0;
+        return v >= 1 && v <= 24 ? v : 24;
+    }();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(eigen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EJ_LDS_BYTES);
-    hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), EJ_LDS_BYTES, stream, S, slot, sqrt_pi, pool, n_states);
+    hipLaunchKernelGGL(eigen_kernel, dim3(M), dim3(256), EJ_LDS_BYTES, stream, S, slot, sqrt_pi, pool, n_states, max_sweeps, status);
 }
 
 // =============================================================================================

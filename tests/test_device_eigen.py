@@ -150,3 +150,34 @@ def test_many_matrices_per_call(gpu_engine_cls):
     print(f"1 998 new rate matrices per call: host solver {out['host'][1] * 1e3:.1f} ms per evaluation, device solver {out['device'][1] * 1e3:.1f} ms")
     assert out["host"][2] == out["device"][2] >= 5 * 1998
     assert np.abs(np.array(out["host"][0]) - np.array(out["device"][0])).max() < 1e-6 * 10
+
+
+def test_a_matrix_that_does_not_converge_fails_the_call():
+    """Kernel 0 reports a matrix still rotating after its last sweep; the engine fails the call with the eigen status and
+    forgets the slots (checked in a child process with the sweep limit lowered to 2: CRAB_EIGEN_MAX_SWEEPS)."""
+    import subprocess
+    import sys
+    code = """
+import numpy as np
+from crabml_amd import synth
+from crabml_amd._lib import CrabError, CRAB_ERR_EIGEN
+from crabml_amd.engine import Engine
+case = synth.make_case("M8", 12, 200, seed=3)
+with Engine(0) as eng:
+    eng.set_eigensolver("device")
+    eng.set_tree(case.parent, case.leaf_node_ids)
+    eng.set_alignment(case.codes)
+    for attempt in range(2):
+        try:
+            eng.codon_site_classes(case.kappa, case.class_omegas, case.proportions, case.pi, case.branch_lengths)
+        except CrabError as e:
+            assert e.status == CRAB_ERR_EIGEN and "did not converge" in str(e), (e.status, str(e))
+        else:
+            raise SystemExit("no error")
+    assert eng.eig_pool_stats()[2] == 0, eng.eig_pool_stats()      # nothing was kept
+    eng.set_eigensolver("host")
+    print("host", eng.codon_site_classes(case.kappa, case.class_omegas, case.proportions, case.pi, case.branch_lengths))
+"""
+    env = dict(os.environ, CRAB_EIGEN_MAX_SWEEPS="2", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("host -"), out.stdout + out.stderr
