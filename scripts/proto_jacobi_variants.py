@@ -1,3 +1,7 @@
+"""numpy prototypes behind kernel 0's design (round 2): one-sided (Hestenes) against two-sided cyclic Jacobi with the same
+round-robin pairing, on symmetrised codon rate matrices.  The one-sided variant needs 11-14 sweeps (some omega values more)
+where the two-sided one needs 8-10, and wants an absolute floor for the null column; kernel 0 is two-sided.
+    python scripts/proto_jacobi_variants.py"""
 import numpy as np, sys, os
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from crabml_amd import synth
@@ -74,5 +78,20 @@ def P_of(lam, V, pi, t):
     return (V / sq[:, None]) @ np.diag(np.exp(lam * t)) @ (V * sq[:, None]).T
 
 if __name__ == "__main__":
-    import mpmath
-    from crabml_amd.models import build_codon_q  # may not exist
+    from crabml_amd import models as m
+    rng = np.random.default_rng(1)
+    for trial in range(4):
+        pi = rng.dirichlet(np.ones(61) * (0.3 if trial % 2 else 3.0))
+        kappa = rng.uniform(0.5, 8)
+        for omega in (1e-6, 1e-3, 0.05, 0.5, 1.0, 2.5, 20.0):
+            Q = m.build_codon_Q_matrix(kappa, omega, pi)
+            sq = np.sqrt(pi)
+            S = (Q * sq[:, None]) / sq[None, :]
+            S = 0.5 * (S + S.T)
+            lr, Vr = np.linalg.eigh(S)
+            row = []
+            for name, f in (("one-sided", hestenes), ("two-sided", two_sided)):
+                lam, V, sw = f(S)
+                row.append(f"{name}: {sw} sweeps, residual {np.abs(S @ V - V * lam).max() / np.abs(S).max():.1e}, "
+                           f"orthogonality {np.abs(V.T @ V - np.eye(61)).max():.1e}")
+            print(f"kappa {kappa:.2f} omega {omega:g}: " + "; ".join(row))
