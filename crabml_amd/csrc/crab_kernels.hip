@@ -35,86 +35,102 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // =============================================================================================
 // kernel 1: batched transition matrices
 // =============================================================================================
-// One workgroup (4 waves) per matrix; wave w produces rows i in [16w, 16w+16) of P.
+// One workgroup (4 waves) builds `per_wg` consecutive matrices of the list; wave w produces rows i in [16w, 16w+16) of P.
 // It computes the transposed tiles D^T[j][i] = sum_k Uinv[k][j] * (U[i][k] e^{lam_k t}) with
 // A = Uinv^T (M index = j), B = (U diag)^T (N index = i) on v_mfma_f64_16x16x4_f64: with the f64 C/D map
 // (col = lane&15, row = (lane>>4) + 4*reg) lane l / register r of tile jt holds
-// P[16w + (l&15)][16jt + 4r + (l>>4)], stored into both images of crab_kernels.h.  (This kernel is ~1 % of an
-// evaluation; the stores are 8-byte scatters.)
-__global__ __launch_bounds__(256) void build_p_kernel(const double *__restrict__ eig, const int32_t *__restrict__ eig_id,
+// P[16w + (l&15)][16jt + 4r + (l>>4)], stored into both images of crab_kernels.h with 16-byte stores.
+// The A operand (64 scattered 8-byte loads per lane, two thirds of the kernel's loads) depends on the eigensystem only and
+// stays in registers while consecutive matrices share one -- all branches of a site class do.  The 64 exponentials of a
+// matrix are computed by one wave and shared through LDS (every lane used to compute the 16 it needs: 16-fold redundant,
+// and at ~250 cycles per fp64 exp more work than the kernel's MFMAs).
+__global__ __launch_bounds__(256, 2) void build_p_kernel(const double *__restrict__ eig, const int32_t *__restrict__ eig_id,
                                                       const double *__restrict__ t_eff, double *__restrict__ P, int n_states,
-                                                      int clamp_negative)
+                                                      int clamp_negative, int M, int per_wg)
 {
-    const int m = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int mt = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const double *E = eig + (size_t)eig_id[m] * EIG_STRIDE;
-    const double *UT = E + EIG_UT, *Uinv = E + EIG_UINV, *lam = E + EIG_LAM;
-    const double t = t_eff[m];
-
-    v4d acc[4];
+    const int ns_jt = n_states >> 4, ns_r = (n_states >> 2) & 3, ns_g = n_states & 3;
+    const int i = 16 * mt + c;
+    const bool hi_half = (c & 4) != 0;
+    const int m0 = blockIdx.x * per_wg, m1 = m0 + per_wg < M ? m0 + per_wg : M;
+    __shared__ double ex[2][NS];   // e^{lam_k t} of the current matrix: 64 values, computed once (not once per lane that uses them)
+    double a[16][4];
+    int cur = -1;
+    for (int m = m0; m < m1; ++m) {
+        const int id = __builtin_amdgcn_readfirstlane(eig_id[m]);
+        const double *E = eig + (size_t)id * EIG_STRIDE;
+        const double *UT = E + EIG_UT, *Uinv = E + EIG_UINV, *lam = E + EIG_LAM;
+        if (id != cur) {
+            cur = id;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) acc[jt] = (v4d){0.0, 0.0, 0.0, 0.0};
-
+            for (int s = 0; s < 16; ++s)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int k = 4 * s + g;
-        const double b = UT[k * NS + 16 * mt + c] * exp(lam[k] * t);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const double a = Uinv[k * NS + 16 * jt + c];
-            acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+                for (int jt = 0; jt < 4; ++jt) a[s][jt] = Uinv[(4 * s + g) * NS + 16 * jt + c];
         }
-    }
-    // exp(Qt) >= 0; the eigen route leaves entries of -1e-15 where the true value is (near) zero, e.g. everywhere off
-    // the diagonal at t = 0.  The pruning pass rescales each pattern by its largest *positive* entry, so data that such
-    // a matrix makes impossible would otherwise blow negative noise up into infinities: evaluations clamp it to zero
-    // (as PAML does); crab_matrix_exponential returns the raw values like the reference (matrix.rs:88-102).
-    if (clamp_negative) {
+        const double t = t_eff[m];
+        if (threadIdx.x < NS) ex[m & 1][threadIdx.x] = exp(lam[threadIdx.x] * t);
+        __syncthreads();   // (two buffers: the readers of this one, two matrices ago, have passed the barrier in between)
+
+        v4d acc[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[jt] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 4 * s + g;
+            const double b = UT[k * NS + 16 * mt + c] * ex[m & 1][k];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][jt], b, acc[jt], 0, 0, 0);
+        }
+        // exp(Qt) >= 0; the eigen route leaves entries of -1e-15 where the true value is (near) zero, e.g. everywhere off
+        // the diagonal at t = 0.  The pruning pass rescales each pattern by its largest *positive* entry, so data that such
+        // a matrix makes impossible would otherwise blow negative noise up into infinities: evaluations clamp it to zero
+        // (as PAML does); crab_matrix_exponential returns the raw values like the reference (matrix.rs:88-102).
+        if (clamp_negative) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[jt][r] = acc[jt][r] < 0.0 ? 0.0 : acc[jt][r];
+        }
+        // row sums over the real states (padded columns are exact zeros)
+        double rs = 0.0;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[jt][r] = acc[jt][r] < 0.0 ? 0.0 : acc[jt][r];
+            for (int r = 0; r < 4; ++r) rs += acc[jt][r];
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        // column n_states (a padding column, zero so far) receives the row sum
+        double *out = P + (size_t)m * P_ELEMS;
+        // 16-byte stores.  Operand image: registers r, r+1 (r even) of a lane are neighbours there (the (j>>2)&1 bit).
+        // Gather image: rows i and i^4 are neighbours (the (i>>2)&1 bit) and live in lanes c and c^4, so each pair of lanes
+        // swaps one value per register pair: the lane with bit 2 of c clear stores column j(r), the other column j(r+1).
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                double v0 = acc[jt][r], v1 = acc[jt][r + 1];
+                if (jt == ns_jt && r == ns_r && g == ns_g) v0 = rs;
+                if (jt == ns_jt && r + 1 == ns_r && g == ns_g) v1 = rs;
+                const int j0 = 16 * jt + 4 * r + g, j1 = j0 + 4;
+                *(v2d *)(out + p_operand_index(i, j0)) = (v2d){v0, v1};
+                // what the partner lane (c ^ 4) needs from this lane: its column is j1 if this lane is the low half, j0 otherwise
+                const double give = hi_half ? v0 : v1;
+                const double got = __shfl_xor(give, 4);
+                const v2d pair = hi_half ? (v2d){got, v1} : (v2d){v0, got};
+                *(v2d *)(out + p_gather_index(i & ~4, hi_half ? j1 : j0)) = pair;
+            }
     }
-    // row sums over the real states (padded columns are exact zeros)
-    double rs = 0.0;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rs += acc[jt][r];
-    rs += __shfl_xor(rs, 16);
-    rs += __shfl_xor(rs, 32);
-    // column n_states (a padding column, zero so far) receives the row sum
-    const int ns_jt = n_states >> 4, ns_r = (n_states >> 2) & 3, ns_g = n_states & 3;
-    double *out = P + (size_t)m * P_ELEMS;
-    const int i = 16 * mt + c;
-    // 16-byte stores.  Operand image: registers r, r+1 (r even) of a lane are neighbours there (the (j>>2)&1 bit).
-    // Gather image: rows i and i^4 are neighbours (the (i>>2)&1 bit) and live in lanes c and c^4, so each pair of lanes
-    // swaps one value per register pair: the lane with bit 2 of c clear stores column j(r), the other column j(r+1).
-    const bool hi_half = (c & 4) != 0;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            double v0 = acc[jt][r], v1 = acc[jt][r + 1];
-            if (jt == ns_jt && r == ns_r && g == ns_g) v0 = rs;
-            if (jt == ns_jt && r + 1 == ns_r && g == ns_g) v1 = rs;
-            const int j0 = 16 * jt + 4 * r + g, j1 = j0 + 4;
-            *(v2d *)(out + p_operand_index(i, j0)) = (v2d){v0, v1};
-            // what the partner lane (c ^ 4) needs from this lane: its column is j1 if this lane is the low half, j0 otherwise
-            const double give = hi_half ? v0 : v1;
-            const double got = __shfl_xor(give, 4);
-            const v2d pair = hi_half ? (v2d){got, v1} : (v2d){v0, got};
-            *(v2d *)(out + p_gather_index(i & ~4, hi_half ? j1 : j0)) = pair;
-        }
 }
 
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
                     bool clamp_negative, hipStream_t stream)
 {
     if (M <= 0) return;
-    hipLaunchKernelGGL(build_p_kernel, dim3(M), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0);
+    // one round of workgroups (two fit a CU at this kernel's register count), each with a run of the matrix list
+    const int per_wg = (M + 511) / 512, grid = (M + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(build_p_kernel, dim3(grid), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0, M, per_wg);
 }
 
 // =============================================================================================
