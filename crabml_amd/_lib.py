@@ -29,6 +29,8 @@ SIGNATURES = {
     "crab_create_multi": (C.c_int, [ip, C.c_int, C.POINTER(vp)]),
     "crab_n_devices": (C.c_int, [vp]),
     "crab_set_eigensolver": (C.c_int, [vp, C.c_int]),
+    "crab_set_clade_tables": (C.c_int, [vp, C.c_int]),
+    "crab_last_clade_tables": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "crab_destroy": (None, [vp]),
     "crab_last_error": (C.c_char_p, [vp]),
     "crab_device_available": (C.c_int, []),

@@ -426,6 +426,18 @@ struct TreeParts {
     PathProgram root;                     // the rest of the tree
 };
 
+// Clade tables (subtree site repeats; build_clade_tables).  A clade whose leaves show few distinct sub-patterns is walked
+// once per sub-pattern; the message of its root's branch goes into a table that the main program reads like a leaf edge.
+struct CladeTables {
+    bool built = false;              // for the engine's current tree and alignment (an empty set is a valid outcome)
+    std::vector<int> roots;          // clade root nodes in program order; clade j's wide row is alignment row aln_rows + j
+    std::vector<int64_t> U, tiles;   // distinct sub-patterns per clade, and ceil(U / tile width)
+    std::vector<int> slot_off;       // first 64 KiB slot of clade j's table inside one class's run of table slots
+    int slots_per_class = 0;
+    std::vector<PathProgram> progs;  // per clade: its subtree, the product on its root's branch, the table store
+    PathProgram main;                // the tree with every clade replaced by a table leaf
+};
+
 struct crab_engine : TreeProgram {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -441,6 +453,12 @@ struct crab_engine : TreeProgram {
                                              // (path programs, or root programs); 0: one launch
     int64_t dev_bounds_first[9] = {0}, dev_bounds_second[9] = {0};   // per-XCD chunks of the two launches' work items
     int dev_part_target = 0;            // the tree-part size the uploaded programs were cut for (0: uncut)
+    bool dev_clades = false;            // the uploaded programs are clade programs + main programs
+    int64_t dev_gemm_extra = 0;         // products of the uploaded clade programs, all sub-patterns and classes (not per pattern)
+    CladeTables clades;
+    bool clade_tables_on = true;        // crab_set_clade_tables
+    int last_n_clades = 0;
+    std::vector<uint8_t> h_codes;       // host copy of d_codes: [aln_rows][n_pat_pad]
     TreeParts tree_parts;
     int64_t dev_gemm_per_pat = 0, dev_leaf_per_pat = 0;
     std::unordered_map<int, PathProgram> path_programs;   // by moved node, built on first use
@@ -456,7 +474,9 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_items;
+    DevBuf<uint32_t> d_idx32;
+    DevBuf<uint8_t> d_codes_alt;
     DevBuf<ProgHdr> d_hdr;
     DevBuf<char> d_save;
     int last_n_path = 0, last_n_parts = 0;
@@ -492,7 +512,7 @@ struct crab_engine : TreeProgram {
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_idx32.release(); d_codes_alt.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
         h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -530,6 +550,7 @@ int guarded(crab_engine *e, F &&body)
 }
 
 [[noreturn]] void fail(int code, const std::string &msg) { throw ArgError{code, msg}; }
+uint64_t mix64(uint64_t h, uint64_t v);
 
 // ---------------------------------------------------------------------------------------------
 // tree -> program
@@ -935,6 +956,197 @@ void build_tree_parts(const TreeProgram *e, int target, TreeParts &tp)
     finalise_program(tp.root.ops, tp.root.info);
 }
 
+// Clade tables (subtree site repeats).  On alignments of related sequences the leaves of a small clade show far fewer
+// distinct sub-patterns than the alignment has patterns (configs[1]: a 6-leaf clade ~15 % of 9 953), and everything the
+// pruning pass computes below the clade's root -- its conditional likelihoods and the message of the branch above it --
+// depends on the sub-pattern only.  Chosen clades are therefore walked once per distinct sub-pattern by programs of their
+// own (launch 1: the clade's subtree ops, the product on its root's branch, a store into the clade's table), and the main
+// program (launch 2) replaces subtree and product by one leaf-style gather from that table, indexed per pattern.
+// Same ops, same order, same rescaling points as the whole-tree program; a table entry is the tile the whole walk would
+// hold after that product, with its power-of-two exponent folded in (exact), and every later normalisation brings the
+// running product back to the same mantissas: results are bit-identical to whole walks (tests/test_clade_tables.py).
+// Choice: one level (clades do not nest), at most 16 leaves (the folded exponent stays far inside the fp64 range),
+// minimising products: a clade costs (products below + 1) x padded sub-patterns + a gather per pattern, walking a node
+// costs one product per pattern plus the best of its internal children.
+void build_clade_tables(crab_engine *e)
+{
+    CladeTables &ct = e->clades;
+    ct = CladeTables{};
+    ct.built = true;
+    const int nn = e->n_nodes, tile = prune_tile_width();
+    const int64_t n_pat = e->n_pat, npp = e->n_pat_pad;
+    if (n_pat < 4 * tile || e->n_gemm_edges < 2 || e->h_codes.size() != (size_t)e->aln_rows * npp) return;
+    constexpr int MAX_LEAVES = 16;
+    constexpr double GATHER_COST = 0.15;     // a table gather + multiply per pattern, in products
+    const std::vector<TreeOp> &ops = e->ops;
+    // post-order over the internal nodes = order of their last op
+    std::vector<int> internal;
+    for (int v = 0; v < nn; ++v)
+        if (e->reachable[v] && !e->in_leaf_set[v] && e->op_fin[v] >= 0) internal.push_back(v);
+    std::sort(internal.begin(), internal.end(), [&](int a, int b) { return e->op_fin[a] < e->op_fin[b]; });
+    std::vector<std::vector<int>> rows(nn);          // alignment rows below a node (kept only up to MAX_LEAVES)
+    std::vector<int> n_rows(nn, 0), n_prod(nn, 0);
+    std::vector<int64_t> U(nn, -1);
+    std::vector<double> best(nn, 0.0), as_table(nn, -1.0);
+    // distinct sub-patterns of a set of rows: open addressing on a hash of the (<= 16) bytes
+    size_t cap = 64;
+    while (cap < (size_t)n_pat * 2) cap <<= 1;
+    std::vector<int32_t> slot_pat(cap), ids;
+    std::vector<int64_t> reps;
+    auto distinct = [&](const std::vector<int> &rr, bool want_ids) -> int64_t {
+        std::fill(slot_pat.begin(), slot_pat.end(), -1);
+        if (want_ids) ids.assign(n_pat, 0), reps.clear();
+        int64_t n_u = 0;
+        const int nr = (int)rr.size();
+        for (int64_t p = 0; p < n_pat; ++p) {
+            uint64_t k0 = 0, k1 = 0;
+            for (int i = 0; i < nr; ++i) {
+                const uint64_t c = e->h_codes[(size_t)rr[i] * npp + p];
+                if (i < 8) k0 |= c << (8 * i); else k1 |= c << (8 * (i - 8));
+            }
+            size_t h = (size_t)mix64(mix64(0x51ed270b7a3f11c5ull, k0), k1) & (cap - 1);
+            for (;;) {
+                const int32_t q = slot_pat[h];
+                if (q < 0) {
+                    slot_pat[h] = (int32_t)p;
+                    if (want_ids) ids[p] = (int32_t)n_u, reps.push_back(p);
+                    ++n_u;
+                    break;
+                }
+                bool same = true;
+                for (int i = 0; i < nr && same; ++i) same = e->h_codes[(size_t)rr[i] * npp + q] == e->h_codes[(size_t)rr[i] * npp + p];
+                if (same) {
+                    if (want_ids) ids[p] = ids[q];
+                    break;
+                }
+                h = (h + 1) & (cap - 1);
+            }
+        }
+        return n_u;
+    };
+    for (int v : internal) {
+        bool small = true;
+        double walk = v == e->root ? 0.0 : (double)n_pat;
+        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci) {
+            const int c = e->child[ci];
+            if (e->in_leaf_set[c]) {
+                n_rows[v] += 1;
+                if (small && (int)rows[v].size() < MAX_LEAVES) rows[v].push_back(e->leaf_row[c]);
+            } else {
+                n_rows[v] += n_rows[c];
+                n_prod[v] += n_prod[c] + 1;
+                walk += best[c];
+                if (n_rows[c] > MAX_LEAVES || (U[c] >= 0 && 2 * U[c] > n_pat)) small = false;   // U only grows towards the root
+                if (small) rows[v].insert(rows[v].end(), rows[c].begin(), rows[c].end());
+                std::vector<int>().swap(rows[c]);
+            }
+        }
+        best[v] = walk;
+        if (v == e->root || !small || n_rows[v] < 2 || n_rows[v] > MAX_LEAVES) continue;
+        U[v] = distinct(rows[v], false);
+        const int64_t u_pad = (U[v] + tile - 1) / tile * tile;
+        as_table[v] = (double)(n_prod[v] + 1) * (double)u_pad + GATHER_COST * (double)n_pat;
+        if (as_table[v] < walk) best[v] = as_table[v];
+    }
+    // top-down: the first node on every path from the root that is cheaper as a table
+    std::vector<int> stack{e->root};
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        if (as_table[v] >= 0.0 && best[v] == as_table[v]) {
+            ct.roots.push_back(v);
+            continue;
+        }
+        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci)
+            if (!e->in_leaf_set[e->child[ci]]) stack.push_back(e->child[ci]);
+    }
+    if (ct.roots.empty()) return;
+    std::sort(ct.roots.begin(), ct.roots.end(), [&](int a, int b) { return e->op_begin[a] < e->op_begin[b]; });
+    const int n_cl = (int)ct.roots.size();
+    // per clade: sub-pattern ids per pattern (the wide row), the sub-patterns' codes (the clade's rows of codes_alt)
+    std::vector<uint32_t> idx((size_t)n_cl * npp, 0u);
+    std::vector<uint8_t> alt((size_t)e->aln_rows * npp, (uint8_t)e->n_states);
+    ct.U.resize(n_cl), ct.tiles.resize(n_cl), ct.slot_off.resize(n_cl), ct.progs.resize(n_cl);
+    auto rows_below = [&](int c) {
+        std::vector<int> rr, st{c};
+        while (!st.empty()) {
+            const int v = st.back();
+            st.pop_back();
+            if (e->in_leaf_set[v]) {
+                rr.push_back(e->leaf_row[v]);
+                continue;
+            }
+            for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci) st.push_back(e->child[ci]);
+        }
+        return rr;
+    };
+    int slot = 0;
+    for (int j = 0; j < n_cl; ++j) {
+        const int c = ct.roots[j];
+        const std::vector<int> rr = rows_below(c);
+        ct.U[j] = distinct(rr, true);
+        ct.tiles[j] = (ct.U[j] + tile - 1) / tile;
+        for (int64_t p = 0; p < n_pat; ++p) idx[(size_t)j * npp + p] = (uint32_t)ids[p];
+        for (int r : rr)
+            for (int64_t u = 0; u < ct.U[j]; ++u) alt[(size_t)r * npp + u] = e->h_codes[(size_t)r * npp + reps[u]];
+        // a table is addressed like the gather image of a (pseudo) matrix: it starts half a slot in and runs on
+        ct.slot_off[j] = slot;
+        slot += (int)((P_IMAGE * sizeof(double) + (size_t)ct.tiles[j] * tile * 512 + P_ELEMS * sizeof(double) - 1) / (P_ELEMS * sizeof(double)));
+    }
+    ct.slots_per_class = slot;
+    // programs
+    auto plain = [&](int i) {
+        TreeOp o = ops[i];
+        o.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
+        o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
+        return o;
+    };
+    size_t next = 0;
+    for (int i = 0; i < (int)ops.size();) {
+        if (next < ct.roots.size() && i == e->op_begin[ct.roots[next]]) {
+            const int c = ct.roots[next], gi = e->gemm_op_of[c];
+            PathProgram &pp = ct.progs[next];
+            for (int k = e->op_begin[c]; k <= e->op_fin[c]; ++k) pp.ops.push_back(plain(k));
+            TreeOp g = plain(gi);                 // the message of the branch above the clade: P_c L_c, nothing else
+            g.flags = 0;
+            g.slot = 0;
+            pp.ops.push_back(g);
+            TreeOp st{};
+            st.kind = OP_LOAD;
+            st.node = -1;
+            st.flags = F_SAVE | F_TABLE;
+            st.arg = (int)next;
+            st.pre_node = st.pre_node_b = st.pre_row2 = st.pre_row3 = -1;
+            pp.ops.push_back(st);
+            finalise_program(pp.ops, pp.info);
+            // the main program: the table stands where the product stood -- multiplied into the parent's running product if
+            // the product popped one (then nothing needs the push that saved it), with the product's rescale / push / last-term flags
+            const TreeOp &gw = ops[gi];
+            TreeOp leaf{};
+            leaf.kind = OP_LEAF;
+            leaf.node = c;
+            leaf.arg = e->aln_rows + (int)next;
+            leaf.flags = (gw.flags & (F_RESCALE | F_FIN | F_PUSH)) | ((gw.flags & F_POP_MUL) ? F_MUL_PROD : 0);
+            leaf.slot = gw.slot;
+            leaf.pre_node = leaf.pre_node_b = leaf.pre_row2 = leaf.pre_row3 = -1;
+            if ((gw.flags & F_POP_MUL) && !ct.main.ops.empty()) ct.main.ops.back().flags &= ~F_PUSH;
+            ct.main.ops.push_back(leaf);
+            i = gi + 1;
+            ++next;
+        } else {
+            ct.main.ops.push_back(plain(i));
+            ++i;
+        }
+    }
+    finalise_program(ct.main.ops, ct.main.info);
+    HIP_CHECK(hipSetDevice(e->device));
+    e->d_idx32.ensure(idx.size());
+    e->d_codes_alt.ensure(alt.size());
+    HIP_CHECK(hipMemcpyAsync(e->d_idx32.p, idx.data(), idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipMemcpyAsync(e->d_codes_alt.p, alt.data(), alt.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
 // Packs one program for the device: matrix indices (through pk, the program's node -> matrix table) instead of node
 // ids, and on each leaf edge the alignment row of the leaf edge after it (whose codes the kernel requests one edge
 // ahead).  `save`: GEMM ops store their tiles in the save area (the base vector of a batch with partial updates).
@@ -1094,6 +1306,9 @@ void upload_alignment(crab_engine *e, const CompressedAlignment &ca, int64_t pat
     HIP_CHECK(hipMemcpyAsync(e->d_codes.p, img.data(), img.size(), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipMemcpyAsync(e->d_weights.p, e->weights.data(), e->n_pat_pad * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->h_codes.swap(img);
+    e->clades = CladeTables{};
+    e->dev_ops.clear();
     e->have_aln = true;
 }
 
@@ -1148,6 +1363,11 @@ bool path_updates_disabled()
 bool tree_parts_disabled()
 {
     const char *sv = std::getenv("CRAB_NO_TREE_PARTS");
+    return sv && sv[0] && sv[0] != '0';
+}
+bool clade_tables_disabled()
+{
+    const char *sv = std::getenv("CRAB_NO_CLADE_TABLES");
     return sv && sv[0] && sv[0] != '0';
 }
 // Largest save area the partial-update path may allocate (CRAB_PATH_SAVE_GB, default 96 of the 288 GB)
@@ -1415,8 +1635,16 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     // ---- tree parts (a finer work quantum): a single evaluation with few work items per resident workgroup is cut into
     // subtree programs plus a root program (build_tree_parts) ----
+    // ---- clade tables (subtree site repeats; build_clade_tables): single evaluations only -- in a batch the path programs of
+    // partial updates want every internal edge's tiles per pattern ----
+    bool use_clades = false;
+    if (G == 1 && prune_supports_paths() && e->clade_tables_on && !clade_tables_disabled() && e->n_pat > 0) {
+        if (!e->clades.built) build_clade_tables(e);
+        use_clades = !e->clades.roots.empty();
+    }
+    const int n_cl = use_clades ? (int)e->clades.roots.size() : 0;
     int part_target = 0;
-    if (G == 1 && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
+    if (G == 1 && !use_clades && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
         const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device), n_work = n_tiles * pl.K;
         // measured (profiles/r2_tree_parts_timing.txt): a gain below ~3 items per resident workgroup (+15 % at config 3's
         // per-GPU share, +43 % at config 4's, +10 % at config 4 in full), a small loss at configs[1]'s 3.35
@@ -1441,11 +1669,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     }
     const int n_parts = part_target > 0 ? n_cut : 0;
-    const int n_prog = pl.K * (1 + n_parts);       // programs 0 .. K-1 write the site likelihoods; part (k, i) is program K + k * n_parts + i
+    // programs 0 .. K-1 write the site likelihoods; part / clade (k, i) is program K + k * n_parts + i
+    const int n_prog = pl.K * (1 + (use_clades ? n_cl : n_parts));
 
     // ---- uploads ----
     const size_t prog_stride = (size_t)dev_ops_padded((int64_t)e->ops.size());
-    if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node || part_target != e->dev_part_target) {
+    if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node || part_target != e->dev_part_target ||
+        use_clades != e->dev_clades) {
         // the programs depend on the tree and on these tables only
         DevOp filler{};
         filler.w0 = OP_CONST;
@@ -1466,7 +1696,60 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         whole.n_gemm = (int)e->n_gemm_edges, whole.n_leaf = (int)e->n_leaf_edges;
         int n_first = 0;
         e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
-        if (n_parts > 0) {
+        e->dev_gemm_extra = 0;
+        std::vector<int32_t> items;                 // launch 1 of clade tables: (list entry, tile) per work item
+        if (use_clades) {
+            const CladeTables &ct = e->clades;
+            std::vector<int32_t> pk_main(nn);
+            for (int k = 0; k < pl.K; ++k) {
+                const int32_t *pk = pidx->data() + (size_t)k * nn;
+                std::copy(pk, pk + nn, pk_main.begin());
+                for (int j = 0; j < n_cl; ++j) {
+                    const int32_t table_mat = M + k * ct.slots_per_class + ct.slot_off[j];
+                    pk_main[ct.roots[j]] = table_mat;           // the main program gathers from the table as from a leaf edge's image
+                    const int prog = pl.K + k * n_cl + j;
+                    DevOp *po = progs.data() + (size_t)prog * prog_stride;
+                    resolve_program(ct.progs[j].ops, pk, false, po);
+                    po[ct.progs[j].ops.size() - 1].mat = table_mat;   // the table store
+                    header(prog, ct.progs[j].info, k, 1);
+                    hdrs[prog].alt_codes = 1;
+                }
+                resolve_program(ct.main.ops, pk_main.data(), false, progs.data() + (size_t)k * prog_stride);
+                header(k, ct.main.info, k, 0);
+            }
+            // launch 1: class-major (one class's matrices stay together), clades with most products first
+            std::vector<int> order(n_cl);
+            for (int j = 0; j < n_cl; ++j) order[j] = j;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ct.progs[x].info.n_gemm > ct.progs[y].info.n_gemm; });
+            std::vector<double> item_w;
+            for (int k = 0; k < pl.K; ++k)
+                for (int j : order) {
+                    const int entry = (int)lists.size();
+                    lists.push_back(pl.K + k * n_cl + j);
+                    const ProgInfo &in = ct.progs[j].info;
+                    for (int64_t t = 0; t < ct.tiles[j]; ++t) {
+                        items.push_back(entry);
+                        items.push_back((int32_t)t);
+                        item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
+                    }
+                    e->dev_gemm_extra += (int64_t)in.n_gemm * ct.tiles[j] * prune_tile_width();
+                }
+            n_first = (int)lists.size();
+            for (int k = 0; k < pl.K; ++k) lists.push_back(k);
+            {   // one chunk of launch 1's items per XCD, of equal work
+                double total = 0.0, acc = 0.0;
+                for (double w : item_w) total += w;
+                int x = 1;
+                e->dev_bounds_first[0] = 0;
+                for (size_t i = 0; i < item_w.size() && x < 8; ++i) {
+                    acc += item_w[i];
+                    while (x < 8 && acc >= total * x / 8.0) e->dev_bounds_first[x++] = (int64_t)i + 1;
+                }
+                while (x <= 8) e->dev_bounds_first[x++] = (int64_t)item_w.size();
+            }
+            e->dev_gemm_per_pat = (int64_t)pl.K * ct.main.info.n_gemm;
+            e->dev_leaf_per_pat = (int64_t)pl.K * ct.main.info.n_leaf;
+        } else if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
                 const int32_t *pk = pidx->data() + (size_t)k * nn;
@@ -1548,8 +1831,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             out[8] = (int64_t)(hi - lo) * n_tiles;
             for (int y = 1; y <= 8; ++y) out[y] = std::max(out[y], out[y - 1]);
         };
-        bounds(0, n_first, e->dev_bounds_first);
+        if (!use_clades) bounds(0, n_first, e->dev_bounds_first);
         bounds(n_first, (int)lists.size(), e->dev_bounds_second);
+        e->dev_clades = use_clades;
+        e->d_items.ensure(items.size() + 2);
+        if (!items.empty())
+            HIP_CHECK(hipMemcpyAsync(e->d_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         e->dev_pidx = *pidx;
         e->dev_vec_node = vec_node;
         e->dev_part_target = part_target;
@@ -1580,8 +1867,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_small.ensure(n_small);
     double *d_teff = e->d_small.p, *d_pi = d_teff + M, *d_props = d_pi + NS;
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
-    e->d_P.ensure((size_t)M * P_ELEMS);
-    const int grid = prune_grid_size(n_tiles * n_first, e->device);
+    e->d_P.ensure(((size_t)M + (use_clades ? (size_t)pl.K * e->clades.slots_per_class : 0)) * P_ELEMS);
+    int64_t n_items_first = n_tiles * n_first;
+    if (use_clades) {
+        n_items_first = 0;
+        for (int64_t t : e->clades.tiles) n_items_first += t * pl.K;
+    }
+    const int grid = prune_grid_size(n_items_first, e->device);
     const int grid_second = two_launches ? prune_grid_size(n_tiles * n_second, e->device) : 0;
     e->d_stack.ensure(prune_stack_doubles(std::max(grid, grid_second), e->max_depth));
     e->d_stack_e.ensure(prune_stack_ints(std::max(grid, grid_second), e->max_depth));
@@ -1630,12 +1922,24 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.first_leaf_op = e->first_leaf_op;
     pa.second_leaf_row = e->second_leaf_row;
     pa.third_leaf_row = e->third_leaf_row;
+    if (use_clades) {     // launch 1: the clade programs, over each clade's distinct sub-patterns
+        pa.items = e->d_items.p;
+        pa.n_items = n_items_first;
+        pa.codes_alt = e->d_codes_alt.p;
+        pa.save = nullptr;
+    }
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     launch_prune(pa, grid, e->stream);
-    if (two_launches) {   // path programs / root programs read what the first launch saved: same stream, after it
+    if (two_launches) {   // path programs / root programs / main programs read what the first launch left: same stream, after it
         pa.K = n_second;
         pa.cls_list = e->d_cls.p + n_first;
         std::copy(e->dev_bounds_second, e->dev_bounds_second + 9, pa.xcd_bounds);
+        if (use_clades) {
+            pa.items = nullptr;
+            pa.n_items = 0;
+            pa.idx32 = e->d_idx32.p;
+            pa.n_code_rows = e->aln_rows;
+        }
         launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
@@ -1762,10 +2066,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_pidx = *pidx;
     e->last_K = pl.K;
     e->last_M = M;
-    e->last_dense = e->dev_gemm_per_pat * e->n_pat;     // products and gathers actually executed
+    e->last_dense = e->dev_gemm_per_pat * e->n_pat + e->dev_gemm_extra;     // products and gathers actually executed
     e->last_gather = e->dev_leaf_per_pat * e->n_pat;
     e->last_n_path = n_parts > 0 ? 0 : n_second / std::max(1, Kg);
     e->last_n_parts = n_parts;
+    e->last_n_clades = n_cl;
 
     if (pl.post_weights) {
         const double *src = e->h_out.p + G;
@@ -2021,6 +2326,33 @@ int crab_set_eigensolver(crab_engine *e, int on_device)
 
 int crab_n_devices(const crab_engine *e) { return e ? (e->is_multi() ? (int)e->shards.size() : 1) : 0; }
 
+int crab_set_clade_tables(crab_engine *e, int on)
+{
+    if (!e) return CRAB_ERR_ARG;
+    e->clade_tables_on = on != 0;
+    for (crab_engine *sh : e->shards) sh->clade_tables_on = on != 0;
+    return CRAB_OK;
+}
+
+int crab_last_clade_tables(const crab_engine *e, int *n_clades, int64_t *sub_patterns)
+{
+    if (!e) return CRAB_ERR_ARG;
+    int n = 0;
+    int64_t u = 0;
+    auto add = [&](const crab_engine *x) {
+        n += x->last_n_clades;
+        if (x->last_n_clades > 0)
+            for (int64_t v : x->clades.U) u += v;
+    };
+    if (e->is_multi())
+        for (const crab_engine *sh : e->shards) add(sh);
+    else
+        add(e);
+    if (n_clades) *n_clades = n;
+    if (sub_patterns) *sub_patterns = u;
+    return CRAB_OK;
+}
+
 void crab_destroy(crab_engine *e) { delete e; }
 
 const char *crab_last_error(const crab_engine *e) { return e ? e->err.c_str() : g_last_error.c_str(); }
@@ -2041,6 +2373,7 @@ int crab_set_tree(crab_engine *e, int n_nodes, const int32_t *node_ids, const in
         e->dev_ops.clear();
         e->path_programs.clear();
         e->tree_parts = TreeParts{};
+        e->clades = CladeTables{};
         build_tree(e, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
         e->have_tree = true;
     });

@@ -61,7 +61,9 @@ enum : int32_t {
     // partial updates (a finite-difference stencil row that moves one branch re-walks only the path from that branch to
     // the root, on tiles the base vector's walk left in HBM): see "save area" below
     F_POP_SAVED = 512,  // GEMM with F_POP_MUL (path programs): the saved product is save slot `slot`, not stack slot `slot`
-    F_SAVE = 1024       // GEMM (base vector's program): store this edge's tiles in save slots sv, sv+1, sv+2
+    F_SAVE = 1024,      // GEMM (base vector's program): store this edge's tiles in save slots sv, sv+1, sv+2
+    F_TABLE = 2048      // OP_LOAD with F_SAVE (clade programs): the current tile, its exponents folded in, becomes 16 columns of the
+                        // clade's table (a gather image of as many columns as the clade shows distinct sub-patterns), at matrix `mat`
 };
 constexpr int OP_FLAG_BITS = 12;   // DevOp::w0 = kind | flags << 2 | slot << (2 + OP_FLAG_BITS)
 // The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
@@ -95,6 +97,8 @@ struct alignas(16) ProgHdr {
     int32_t first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row;   // as in PruneArgs
     int32_t save_cls;  // class index inside the save area (the base vector's class with the same rate matrices)
     int32_t no_root;   // 1: a tree part -- the program ends by saving its tile (OP_LOAD with F_SAVE), no site likelihood is written
+    int32_t alt_codes; // 1: a clade program -- its leaf rows are read from PruneArgs::codes_alt (the clade's distinct sub-patterns)
+    int32_t pad[3];
 };
 // Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
 // of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);
@@ -147,6 +151,15 @@ struct PruneArgs {
     int32_t first_leaf_op;    // index of that op if it is op 0 (its columns are requested before the walk starts), else -1
     int32_t second_leaf_row;  // alignment rows of the second and third leaf edges (-1 if none)
     int32_t third_leaf_row;
+    // Clade tables (subtree site repeats).  A clade whose leaves show U << n_pat distinct sub-patterns is walked once per
+    // sub-pattern by a clade program (launch 1, codes_alt, work items from `items`); the message of its root's branch lands in a
+    // table laid out like a gather image of U columns, and the main program reads it like a leaf edge: alignment rows >=
+    // n_code_rows are rows of idx32 (per pattern: the column of its sub-pattern) instead of byte codes.
+    const int32_t *items;     // [n_items][2] (entry of cls_list, pattern tile) per work item, or nullptr: entry-major, every tile
+    int64_t n_items;
+    const uint8_t *codes_alt; // [n_rows][n_pat_pad] like codes
+    const uint32_t *idx32;    // [n_clades][n_pat_pad]
+    int32_t n_code_rows;      // rows of `codes`; 0 = no wide rows in this launch
 };
 // Stack slots the configured pruning kernel keeps in registers (the schedule must not park columns in the landing
 // tile of a product that pops a deeper, global-memory slot), and whether it has a prefetch tile at all.

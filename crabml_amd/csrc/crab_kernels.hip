@@ -770,6 +770,8 @@ struct Walk {
     unsigned code_off[NT];     // code queue: byte offset of the column inside a gather image, per pattern group, for
     unsigned code_off2[NT];    //   the next leaf edge whose columns are not requested yet, and the one after it
     const uint8_t *codes;      // this lane's column of the code table
+    const uint32_t *idx;       // this lane's column of the wide rows (clade tables), or nullptr
+    size_t table_off;          // this wave's 16 columns inside a clade table: (tile * 4 + wave) * 8192 bytes
     const char *gather0;       // gather image of matrix 0
     char *stack;               // this wave's stack area (uniform) ...
     int32_t *stack_e;          // ... and this lane's element of its exponent area
@@ -790,16 +792,22 @@ struct Walk {
 template <int NT>
 __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, unsigned (&off)[NT])
 {
-    const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
     unsigned code[NT];
+    if (w.a.n_code_rows > 0 && row >= w.a.n_code_rows) {   // a clade's table: the column of this pattern's sub-pattern (wave-uniform branch)
+        const uint32_t *r = w.idx + (size_t)(row - w.a.n_code_rows) * w.a.n_pat_pad;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+    } else {
+        const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
 #ifdef CRAB_ABLATE_CODES   // timing experiment only (wrong results): no load, so no wait for one either
-        code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
-        (void)r;
+            code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
+            (void)r;
 #else
-        code[nt] = r[nt * 16];
+            code[nt] = r[nt * 16];
 #endif
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
@@ -1050,7 +1058,14 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
         } else if (kind == OP_LOAD) {   // a tile another walk saved (path programs, tree parts), or (F_SAVE) saved by this one
             if constexpr (NT == 1 && PATH_OPS) {
                 int es[NT];
-                if (flags & F_SAVE) {
+                if ((flags & (F_SAVE | F_TABLE)) == (F_SAVE | F_TABLE)) {
+                    // the clade's message for 16 sub-patterns: fold the exponents in (exact: a clade is a few leaves deep) and
+                    // store the tile as 16 columns of the table the main program gathers from
+                    int ex = eX[0];
+                    ex = ex < -1022 ? -1022 : ex > 1023 ? 1023 : ex;
+                    t_scale_seq<X>(__hiloint2double((1023 + ex) << 20, 0), std::make_integer_sequence<int, 16>{});
+                    t_store<NT, X>((char *)w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8) + w.table_off, w.stack_voff);
+                } else if (flags & F_SAVE) {
                     save_tile<NT, X>(w, sv, eX);
                 } else if (flags & F_MUL_PROD) {
                     load_saved<NT, Y>(w, sv, es);
@@ -1133,14 +1148,21 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
     const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
     for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
-        const int ci = (int)(wi / n_tiles);
-        const long long tile = wi - (long long)ci * n_tiles;
+        int ci;
+        long long tile;
+        if (a.items) {
+            ci = a.items[2 * wi], tile = a.items[2 * wi + 1];
+        } else {
+            ci = (int)(wi / n_tiles);
+            tile = wi - (long long)ci * n_tiles;
+        }
         const int cls = a.cls_list ? a.cls_list[ci] : ci;
         int n_ops = a.n_ops, first_gemm_op = a.first_gemm_op, first_leaf_row = a.first_leaf_row, first_leaf_op = a.first_leaf_op,
-            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls, no_root = 0;
+            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls, no_root = 0, alt_codes = 0;
         if (a.hdr) {
             const ProgHdr h = a.hdr[cls];
             no_root = h.no_root;
+            alt_codes = h.alt_codes;
             n_ops = h.n_ops, first_gemm_op = h.first_gemm_op, first_leaf_row = h.first_leaf_row, first_leaf_op = h.first_leaf_op;
             second_leaf_row = h.second_leaf_row, third_leaf_row = h.third_leaf_row, save_cls = h.save_cls;
         }
@@ -1150,7 +1172,9 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.ops = a.ops + (size_t)cls * a.n_ops_pad;
         w.ip = 0;
         w.buf = 0;
-        w.codes = a.codes + pat0;
+        w.codes = (alt_codes ? a.codes_alt : a.codes) + pat0;
+        w.idx = a.idx32 ? a.idx32 + pat0 : nullptr;
+        w.table_off = ((size_t)tile * 4 + wave) * 8192;
         w.gather0 = (const char *)(a.P + P_IMAGE);
         w.stack = (char *)a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_bytes;
         w.stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;

@@ -325,6 +325,16 @@ class Engine:
         self._check(self._lib.crab_eig_pool_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def set_clade_tables(self, on: bool):
+        """Clade tables (subtree site repeats; crab_set_clade_tables): on by default, bit-identical to whole walks."""
+        self._check(self._lib.crab_set_clade_tables(self._h, 1 if on else 0))
+
+    def last_clade_tables(self):
+        """(clades the last evaluation walked once per distinct sub-pattern, sum of their distinct sub-pattern counts)."""
+        n, u = C.c_int(), C.c_int64()
+        self._check(self._lib.crab_last_clade_tables(self._h, C.byref(n), C.byref(u)))
+        return n.value, u.value
+
     def last_partial_updates(self) -> int:
         """Vectors of the last batched evaluation that re-walked only a branch-to-root path (crab_last_partial_updates)."""
         n = C.c_int()

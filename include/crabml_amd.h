@@ -83,6 +83,14 @@ int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
  * solvers agree to the accuracy of either (P entries within 2e-14); within one setting batched and single evaluations
  * stay bit-identical.  The environment variable CRAB_DEVICE_EIGEN=1 sets the default of new engines. */
 int crab_set_eigensolver(crab_engine *e, int on_device);
+/* Clade tables (subtree site repeats; on by default, CRAB_NO_CLADE_TABLES=1 switches them off for every engine).  The reference
+ * computes every column at every node (likelihood.rs:176-195).  A single evaluation (one parameter vector) instead walks each
+ * chosen clade -- a subtree of at most 16 leaves whose leaves show few distinct sub-patterns -- once per distinct sub-pattern
+ * and lets the rest of the tree gather the clade's message per pattern; bit-identical to whole walks, a multiple fewer
+ * products on alignments of related sequences.  crab_last_clade_tables: clades used by the last evaluation (0: whole walks)
+ * and the sum of their distinct sub-pattern counts (over the shards of a multi-device handle). */
+int crab_set_clade_tables(crab_engine *e, int on);
+int crab_last_clade_tables(const crab_engine *e, int *n_clades, int64_t *sub_patterns);
 /* Shards behind a handle: 1 for crab_create, n_devices for crab_create_multi. */
 int crab_n_devices(const crab_engine *e);
 void crab_destroy(crab_engine *e);
