@@ -2068,7 +2068,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_M = M;
     e->last_dense = e->dev_gemm_per_pat * e->n_pat + e->dev_gemm_extra;     // products and gathers actually executed
     e->last_gather = e->dev_leaf_per_pat * e->n_pat;
-    e->last_n_path = n_parts > 0 ? 0 : n_second / std::max(1, Kg);
+    e->last_n_path = (n_parts > 0 || use_clades) ? 0 : n_second / std::max(1, Kg);
     e->last_n_parts = n_parts;
     e->last_n_clades = n_cl;
 

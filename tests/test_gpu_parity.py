@@ -23,7 +23,7 @@ import os
 import numpy as np
 import pytest
 
-from util import (DATA, GOLDEN, SITE_MODEL_CASES, SITE_RTOL, TOTAL_ATOL, assert_by_class_close, eigen_route_bound, leaf_ids,
+from util import (DATA, GOLDEN, SITE_MODEL_CASES, SITE_RTOL, TOTAL_ATOL, assert_by_class_close, check_work, eigen_route_bound, leaf_ids,
                   load_case, tree_structure)
 
 pytestmark = pytest.mark.gpu
@@ -317,10 +317,10 @@ def test_config2_m8_100x10k_full_size(gpu_engine_cls, oracle, c2_case):
         lnL, site = eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths, return_sites=True)
         again = eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths)
         P0 = eng.export_transition_matrices(10)
-        dense, gather = eng.last_work()
+        work, n_cl = eng.last_work(), eng.last_clade_tables()[0]
         n_pat = eng.n_patterns
     assert again == lnL                                                # run-to-run deterministic
-    assert dense == 97 * n_pat * 11 and gather == 100 * n_pat * 11     # N-3 internal edges, N leaf edges
+    check_work(work, n_cl, 97 * n_pat * 11, 100 * n_pat * 11)          # N-3 internal edges, N leaf edges
     ref, ref_site = oracle.compute_site_class_log_likelihood(list(case.Q), case.proportions, case.pi, case.tree_structure,
                                                              case.branch_lengths, None, case.codes, case.leaf_node_ids,
                                                              return_sites=True)
@@ -708,9 +708,9 @@ def test_config3_branch_site_500_taxa(gpu_engine_cls, oracle):
         P_dev = np.stack([eng.export_transition_matrices(k) for k in range(4)])
         from_params = eng.codon_branch_site(case.kappa, case.omega0, case.omega2, case.p0, case.p1, case.pi, case.branch_lengths,
                                             case.branch_labels)
-        dense, gather = eng.last_work()
+        work, n_cl = eng.last_work(), eng.last_clade_tables()[0]
         n_pat = eng.n_patterns
-    assert dense == 497 * n_pat * 4 and gather == 500 * n_pat * 4
+    check_work(work, n_cl, 497 * n_pat * 4, 500 * n_pat * 4)
     ref, ref_site = oracle.compute_branch_site_log_likelihood(case.Q3[0], case.Q3[1], case.Q3[2], *args, case.pi, case.tree_structure,
                                                               case.branch_lengths, case.branch_labels, None, case.codes,
                                                               case.leaf_node_ids, return_sites=True)
@@ -1201,6 +1201,7 @@ def _full_size_properties(Engine, case, evaluate, tag, n_slices=8):
         again, site2 = evaluate(eng)
         n_pat = eng.n_patterns_total
         dense, gather = eng.last_work()
+        n_clades = eng.last_clade_tables()[0]
         prune_ms = eng.last_timing()[1]
     assert np.isfinite(lnL) and np.isfinite(site).all(), tag
     assert again == lnL and np.array_equal(site, site2), tag
@@ -1227,7 +1228,7 @@ def _full_size_properties(Engine, case, evaluate, tag, n_slices=8):
     with _engine(Engine, case.parent, np.ascontiguousarray(sub[:, perm])) as eng:
         _, sp = evaluate(eng)
     assert np.array_equal(sp, s_c[perm]), tag
-    return lnL, site, dict(n_pat=n_pat, dense=dense, gather=gather, prune_ms=prune_ms)
+    return lnL, site, dict(n_pat=n_pat, dense=dense, gather=gather, n_clades=n_clades, prune_ms=prune_ms)
 
 
 def test_config3_model_a_500x50k_full_size_properties(gpu_engine_cls):
@@ -1239,7 +1240,7 @@ def test_config3_model_a_500x50k_full_size_properties(gpu_engine_cls):
         return eng.branch_site(case.Q3, *args, case.pi, case.branch_lengths, case.branch_labels, return_sites=True)
 
     lnL, site, facts = _full_size_properties(gpu_engine_cls, case, evaluate, "config 3")
-    assert facts["dense"] == 497 * facts["n_pat"] * 4 and facts["gather"] == 500 * facts["n_pat"] * 4
+    check_work((facts["dense"], facts["gather"]), facts["n_clades"], 497 * facts["n_pat"] * 4, 500 * facts["n_pat"] * 4)
     assert -400.0 * 50000 < lnL < -20.0 * 50000
 
 
@@ -1251,7 +1252,7 @@ def test_config4_free_ratio_1000x100k_full_size_properties(gpu_engine_cls):
         return eng.branch(case.Q_per_node, case.pi, case.branch_lengths, no_clamp=True, return_sites=True)
 
     lnL, site, facts = _full_size_properties(gpu_engine_cls, case, evaluate, "config 4")
-    assert facts["dense"] == 997 * facts["n_pat"] and facts["gather"] == 1000 * facts["n_pat"]
+    check_work((facts["dense"], facts["gather"]), facts["n_clades"], 997 * facts["n_pat"], 1000 * facts["n_pat"])
     with _engine(gpu_engine_cls, case.parent, case.codes) as eng:
         from_params = eng.codon_branch(case.kappa, case.omega_per_node, case.pi, case.branch_lengths, no_clamp=True)
     assert abs(from_params - lnL) < 1e-9 * abs(lnL)
@@ -1270,7 +1271,7 @@ def test_target_workload_m8_500x50k(gpu_engine_cls, oracle):
         return eng.site_classes(Q, pr, pi, bl, return_sites=True)
 
     lnL, site, facts = _full_size_properties(gpu_engine_cls, case, evaluate, "target workload")
-    assert facts["dense"] == 497 * facts["n_pat"] * 11 and facts["gather"] == 500 * facts["n_pat"] * 11
+    check_work((facts["dense"], facts["gather"]), facts["n_clades"], 497 * facts["n_pat"] * 11, 500 * facts["n_pat"] * 11)
     cols = np.linspace(0, 49999, 1000).astype(int)
     sub = np.ascontiguousarray(case.codes[:, cols])
     with _engine(gpu_engine_cls, case.parent, sub) as eng:

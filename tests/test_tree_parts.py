@@ -13,6 +13,11 @@ def _engine(Engine, parent, codes, **kw):
     return eng
 
 
+@pytest.fixture(autouse=True)
+def _no_clade_tables(monkeypatch):
+    monkeypatch.setenv("CRAB_NO_CLADE_TABLES", "1")   # they take precedence over tree parts (tests/test_clade_tables.py)
+
+
 def _both(monkeypatch, fn):
     monkeypatch.setenv("CRAB_NO_TREE_PARTS", "1")
     off = fn()

@@ -132,3 +132,12 @@ def eigen_route_bound(oracle, P, pi, ts, codes, leaf, mix, naive=False):
     hi = mix(oracle.site_lnf_from_transition_matrices(P + 2 * EPS_P, pi, ts, codes, leaf, naive=naive))
     with np.errstate(invalid="ignore"):
         return np.where(np.isfinite(lo), hi - lo, np.inf)
+
+
+def check_work(work, n_clades, dense, gather):
+    """Products and gathers the engine reports for its last evaluation: the nominal counts of a whole walk per pattern,
+    or fewer of both when clade tables (subtree site repeats) walked some clades once per distinct sub-pattern."""
+    if n_clades == 0:
+        assert tuple(work) == (dense, gather), (work, dense, gather)
+    else:
+        assert 0 < work[0] < dense and 0 < work[1] < gather, (work, dense, gather)
