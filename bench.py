@@ -132,6 +132,7 @@ def target_workload(device, with_cpu=True, evals=8, cpu_sample=1000):
             prune.append(eng.last_timing()[1])
         dt = (time.perf_counter() - t0) / evals
         dense, gather = eng.last_work()
+        n_clades, sub_patterns = eng.last_clade_tables()
         n_pat = eng.n_patterns
     kernel_ms = float(np.mean(prune))
     tflops = dense * FLOP_PER_UPDATE / (kernel_ms * 1e-3) / 1e12
@@ -140,7 +141,8 @@ def target_workload(device, with_cpu=True, evals=8, cpu_sample=1000):
                        "%.2f subst/codon" % case.tree_length,
            "lnl_evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt, "cl_updates_per_s": updates_per_eval / dt, "patterns": n_pat,
            "prune_kernel_ms": kernel_ms, "prune_tflops": tflops, "roofline_frac": tflops / FP64_MFMA_PEAK_TFLOPS, "lnL": lnL,
-           "dense_updates_per_launch": dense}
+           "executed_dense_updates_per_eval": dense, "whole_walk_dense_updates_per_eval": n_pat * K * (case.n_nodes - 1 - n_taxa),
+           "clades": n_clades, "distinct_sub_patterns": sub_patterns}
     if with_cpu:
         from oracle import oracle as orc
         from oracle import blas_baseline as bb
@@ -271,12 +273,20 @@ def main():
         elapsed = float(t.item())
 
     dense, gather = eng.last_work()
+    n_clades, sub_patterns = eng.last_clade_tables()
     n_pat = eng.n_patterns
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         updates_per_eval = world * N_SITES * n_branches * K           # reference units: every site, every branch, every class
-        kernel_ms = float(np.mean(prune_ms))
-        achieved = dense * FLOP_PER_UPDATE / (kernel_ms * 1e-3) / 1e12
+        # With clade tables (subtree site repeats) a step launches the pruning kernel twice -- clade programs over the clades'
+        # distinct sub-patterns, then the main programs -- and executes fewer products than one per (pattern, internal branch,
+        # class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
+        # stats average); the nominal count of a whole walk stands beside it.
+        launches = 2 if n_clades > 0 else 1
+        kernel_ms_step = float(np.mean(prune_ms))
+        kernel_ms = kernel_ms_step / launches
+        achieved = dense * FLOP_PER_UPDATE / (kernel_ms_step * 1e-3) / 1e12
+        nominal_dense = n_pat * K * (n_branches - N_TAXA)             # products of a whole walk: internal branches only (leaves are gathers)
         out = {
             "metric": "pattern x branch CL updates/sec, M8 (lnL evals/sec alongside)",
             "value": updates_per_eval * args.steps / elapsed,
@@ -298,10 +308,15 @@ def main():
                        "collective": "none" if world == 1 else ("rccl" if backend == "nccl" else backend), "lnL": lnL},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": "prune_kernel_nt1", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_launch": dense * FLOP_PER_UPDATE,
-                         "dense_updates_per_launch": dense, "gathered_leaf_updates_per_launch": gather},
-            "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms,
+                         "kernel": "prune_kernel_nt1", "kernel_ms": kernel_ms, "launches_per_step": launches,
+                         "algorithmic_flop_per_launch": dense * FLOP_PER_UPDATE / launches,
+                         "dense_updates_per_launch": dense / launches, "gathered_leaf_updates_per_launch": gather / launches,
+                         "executed_dense_updates_per_step": dense, "whole_walk_dense_updates_per_step": nominal_dense,
+                         "clade_tables": {"clades": n_clades, "distinct_sub_patterns": sub_patterns,
+                                          "note": "clades of <= 16 leaves are walked once per distinct sub-pattern (launch 1), the main "
+                                                  "programs gather their messages (launch 2); results bit-identical to whole walks "
+                                                  "(tests/test_clade_tables.py); CRAB_NO_CLADE_TABLES=1 restores whole walks"}},
+            "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms_step,
                              "host_eigen": float(np.mean(eigen_ms))},
         }
         if world == 1 and args.fd_batch > 0:

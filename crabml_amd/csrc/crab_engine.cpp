@@ -976,8 +976,15 @@ void build_clade_tables(crab_engine *e)
     const int nn = e->n_nodes, tile = prune_tile_width();
     const int64_t n_pat = e->n_pat, npp = e->n_pat_pad;
     if (n_pat < 4 * tile || e->n_gemm_edges < 2 || e->h_codes.size() != (size_t)e->aln_rows * npp) return;
-    constexpr int MAX_LEAVES = 16;
-    constexpr double GATHER_COST = 0.15;     // a table gather + multiply per pattern, in products
+    auto env_num = [](const char *name, double dflt) {
+        const char *sv = std::getenv(name);
+        return sv && sv[0] ? std::atof(sv) : dflt;
+    };
+    // tuning knobs (experiments: scripts/gpu_clade_sweep.sh); the defaults are the measured optimum at configs[1]
+    const int MAX_LEAVES = std::max(2, std::min(16, (int)env_num("CRAB_CLADE_MAX_LEAVES", 16)));
+    const double GATHER_COST = env_num("CRAB_CLADE_GATHER_COST", 0.15);     // a table gather + multiply per pattern, in products
+    const double PREPASS_COST = env_num("CRAB_CLADE_PREPASS_COST", 1.0);    // a product of a clade program against one of the main program
+    const double ITEM_COST = env_num("CRAB_CLADE_ITEM_COST", 0.0);          // fixed cost of a clade work item (prologue), in products x patterns of a tile
     const std::vector<TreeOp> &ops = e->ops;
     // post-order over the internal nodes = order of their last op
     std::vector<int> internal;
@@ -1045,7 +1052,7 @@ void build_clade_tables(crab_engine *e)
         if (v == e->root || !small || n_rows[v] < 2 || n_rows[v] > MAX_LEAVES) continue;
         U[v] = distinct(rows[v], false);
         const int64_t u_pad = (U[v] + tile - 1) / tile * tile;
-        as_table[v] = (double)(n_prod[v] + 1) * (double)u_pad + GATHER_COST * (double)n_pat;
+        as_table[v] = PREPASS_COST * (double)(n_prod[v] + 1) * (double)u_pad + ITEM_COST * (double)u_pad + GATHER_COST * (double)n_pat;
         if (as_table[v] < walk) best[v] = as_table[v];
     }
     // top-down: the first node on every path from the root that is cheaper as a table
