@@ -65,6 +65,8 @@ SIGNATURES = {
     "crab_compile_tree": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compile_path_program": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compile_tree_part": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crab_compile_clade_tables": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int64, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), ip]),
     "crab_compress_patterns": (C.c_int, [ip, C.c_int, C.c_int64, C.c_int, lp, dp, lp, lp]),
     "crab_host_pool_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crab_spectral_decompose": (C.c_int, [C.c_int, dp, dp, dp, dp, dp]),

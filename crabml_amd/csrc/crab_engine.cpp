@@ -968,14 +968,15 @@ void build_tree_parts(const TreeProgram *e, int target, TreeParts &tp)
 // Choice: one level (clades do not nest), at most 16 leaves (the folded exponent stays far inside the fp64 range),
 // minimising products: a clade costs (products below + 1) x padded sub-patterns + a gather per pattern, walking a node
 // costs one product per pattern plus the best of its internal children.
-void build_clade_tables(crab_engine *e)
+// (host only: `codes` is the byte code table [aln_rows][npp] of the n_pat patterns; idx and alt are the wide rows and the clades'
+// code table to upload)
+void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows, int64_t n_pat, int64_t npp, int n_states,
+                       CladeTables &ct, std::vector<uint32_t> &idx, std::vector<uint8_t> &alt)
 {
-    CladeTables &ct = e->clades;
     ct = CladeTables{};
     ct.built = true;
     const int nn = e->n_nodes, tile = prune_tile_width();
-    const int64_t n_pat = e->n_pat, npp = e->n_pat_pad;
-    if (n_pat < 4 * tile || e->n_gemm_edges < 2 || e->h_codes.size() != (size_t)e->aln_rows * npp) return;
+    if (n_pat < 4 * tile || e->n_gemm_edges < 2) return;
     auto env_num = [](const char *name, double dflt) {
         const char *sv = std::getenv(name);
         return sv && sv[0] ? std::atof(sv) : dflt;
@@ -1008,7 +1009,7 @@ void build_clade_tables(crab_engine *e)
         for (int64_t p = 0; p < n_pat; ++p) {
             uint64_t k0 = 0, k1 = 0;
             for (int i = 0; i < nr; ++i) {
-                const uint64_t c = e->h_codes[(size_t)rr[i] * npp + p];
+                const uint64_t c = codes[(size_t)rr[i] * npp + p];
                 if (i < 8) k0 |= c << (8 * i); else k1 |= c << (8 * (i - 8));
             }
             size_t h = (size_t)mix64(mix64(0x51ed270b7a3f11c5ull, k0), k1) & (cap - 1);
@@ -1021,7 +1022,7 @@ void build_clade_tables(crab_engine *e)
                     break;
                 }
                 bool same = true;
-                for (int i = 0; i < nr && same; ++i) same = e->h_codes[(size_t)rr[i] * npp + q] == e->h_codes[(size_t)rr[i] * npp + p];
+                for (int i = 0; i < nr && same; ++i) same = codes[(size_t)rr[i] * npp + q] == codes[(size_t)rr[i] * npp + p];
                 if (same) {
                     if (want_ids) ids[p] = ids[q];
                     break;
@@ -1071,8 +1072,8 @@ void build_clade_tables(crab_engine *e)
     std::sort(ct.roots.begin(), ct.roots.end(), [&](int a, int b) { return e->op_begin[a] < e->op_begin[b]; });
     const int n_cl = (int)ct.roots.size();
     // per clade: sub-pattern ids per pattern (the wide row), the sub-patterns' codes (the clade's rows of codes_alt)
-    std::vector<uint32_t> idx((size_t)n_cl * npp, 0u);
-    std::vector<uint8_t> alt((size_t)e->aln_rows * npp, (uint8_t)e->n_states);
+    idx.assign((size_t)n_cl * npp, 0u);
+    alt.assign((size_t)aln_rows * npp, (uint8_t)n_states);
     ct.U.resize(n_cl), ct.tiles.resize(n_cl), ct.slot_off.resize(n_cl), ct.progs.resize(n_cl);
     auto rows_below = [&](int c) {
         std::vector<int> rr, st{c};
@@ -1095,7 +1096,7 @@ void build_clade_tables(crab_engine *e)
         ct.tiles[j] = (ct.U[j] + tile - 1) / tile;
         for (int64_t p = 0; p < n_pat; ++p) idx[(size_t)j * npp + p] = (uint32_t)ids[p];
         for (int r : rr)
-            for (int64_t u = 0; u < ct.U[j]; ++u) alt[(size_t)r * npp + u] = e->h_codes[(size_t)r * npp + reps[u]];
+            for (int64_t u = 0; u < ct.U[j]; ++u) alt[(size_t)r * npp + u] = codes[(size_t)r * npp + reps[u]];
         // a table is addressed like the gather image of a (pseudo) matrix: it starts half a slot in and runs on
         ct.slot_off[j] = slot;
         slot += (int)((P_IMAGE * sizeof(double) + (size_t)ct.tiles[j] * tile * 512 + P_ELEMS * sizeof(double) - 1) / (P_ELEMS * sizeof(double)));
@@ -1132,7 +1133,7 @@ void build_clade_tables(crab_engine *e)
             TreeOp leaf{};
             leaf.kind = OP_LEAF;
             leaf.node = c;
-            leaf.arg = e->aln_rows + (int)next;
+            leaf.arg = aln_rows + (int)next;
             leaf.flags = (gw.flags & (F_RESCALE | F_FIN | F_PUSH)) | ((gw.flags & F_POP_MUL) ? F_MUL_PROD : 0);
             leaf.slot = gw.slot;
             leaf.pre_node = leaf.pre_node_b = leaf.pre_row2 = leaf.pre_row3 = -1;
@@ -1146,6 +1147,19 @@ void build_clade_tables(crab_engine *e)
         }
     }
     finalise_program(ct.main.ops, ct.main.info);
+}
+
+void build_clade_tables(crab_engine *e)
+{
+    std::vector<uint32_t> idx;
+    std::vector<uint8_t> alt;
+    if (e->h_codes.size() != (size_t)e->aln_rows * e->n_pat_pad) {
+        e->clades = CladeTables{};
+        e->clades.built = true;
+        return;
+    }
+    plan_clade_tables(e, e->h_codes.data(), e->aln_rows, e->n_pat, e->n_pat_pad, e->n_states, e->clades, idx, alt);
+    if (e->clades.roots.empty()) return;
     HIP_CHECK(hipSetDevice(e->device));
     e->d_idx32.ensure(idx.size());
     e->d_codes_alt.ensure(alt.size());
@@ -2818,6 +2832,52 @@ int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *
                 int32_t *r = ops_out + 6 * i;
                 r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot; r[5] = o.sv;
             }
+        }
+    });
+}
+
+int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                              const int32_t *codes, int64_t n_patterns, int n_states, int part, int32_t *ops_out, int ops_capacity,
+                              int *n_ops, int *n_clades, int *clade_root, int64_t *n_sub_patterns, uint32_t *index_out,
+                              int32_t *sub_codes_out)
+{
+    return guarded(nullptr, [&] {
+        if (!codes || n_patterns < 1 || n_states < 1 || n_states > NS - 1) fail(CRAB_ERR_ARG, "crab_compile_clade_tables: bad arguments");
+        TreeProgram tp;
+        build_tree(&tp, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        const int tile = prune_tile_width();
+        const int64_t npp = (n_patterns + tile - 1) / tile * tile;
+        std::vector<uint8_t> img((size_t)n_leaves * npp, (uint8_t)n_states);
+        for (int r = 0; r < n_leaves; ++r)
+            for (int64_t p = 0; p < n_patterns; ++p) {
+                const int32_t c = codes[(size_t)r * n_patterns + p];
+                img[(size_t)r * npp + p] = (c >= 0 && c < n_states) ? (uint8_t)c : (uint8_t)n_states;
+            }
+        CladeTables ct;
+        std::vector<uint32_t> idx;
+        std::vector<uint8_t> alt;
+        plan_clade_tables(&tp, img.data(), n_leaves, n_patterns, npp, n_states, ct, idx, alt);
+        const int n_cl = (int)ct.roots.size();
+        if (n_clades) *n_clades = n_cl;
+        if (part >= n_cl) fail(CRAB_ERR_ARG, "crab_compile_clade_tables: no such clade");
+        const std::vector<TreeOp> &ops = part < 0 ? ct.main.ops : ct.progs[part].ops;
+        if (n_ops) *n_ops = (int)ops.size();
+        if (ops_out) {
+            if ((int)ops.size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
+            for (size_t i = 0; i < ops.size(); ++i) {
+                const TreeOp &o = ops[i];
+                int32_t *r = ops_out + 6 * i;
+                r[0] = o.kind; r[1] = o.node; r[2] = o.flags; r[3] = o.arg; r[4] = o.slot; r[5] = o.sv;
+            }
+        }
+        if (part >= 0) {
+            if (clade_root) *clade_root = ct.roots[part];
+            if (n_sub_patterns) *n_sub_patterns = ct.U[part];
+            if (index_out)
+                for (int64_t p = 0; p < n_patterns; ++p) index_out[p] = idx[(size_t)part * npp + p];
+            if (sub_codes_out)   // [n_leaves][U]: the codes of the clade's distinct sub-patterns on its own rows, n_states elsewhere
+                for (int r = 0; r < n_leaves; ++r)
+                    for (int64_t u = 0; u < ct.U[part]; ++u) sub_codes_out[(size_t)r * ct.U[part] + u] = alt[(size_t)r * npp + u];
         }
     });
 }

@@ -276,6 +276,15 @@ int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_
  * program, part = i the i-th subtree program, in the 6-field form of crab_compile_path_program. */
 int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
                            int target, int part, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_parts);
+/* Clade tables as programs, for tests (no device needed; `codes` holds the patterns as given, [n_leaves][n_patterns]).  part = -1:
+ * the main program, in which each chosen clade is one leaf-edge op whose alignment row is n_leaves + clade index; part = j >= 0:
+ * clade j's program (its subtree, the product on its root's branch, a store with flags F_SAVE | F_TABLE), with its root node,
+ * its number of distinct sub-patterns U, the sub-pattern index of every pattern (index_out[n_patterns]) and the sub-patterns'
+ * codes (sub_codes_out [n_leaves][U], n_states on rows outside the clade).  Ops as in crab_compile_tree_part. */
+int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                              const int32_t *codes, int64_t n_patterns, int n_states, int part, int32_t *ops_out, int ops_capacity,
+                              int *n_ops, int *n_clades, int *clade_root, int64_t *n_sub_patterns, uint32_t *index_out,
+                              int32_t *sub_codes_out);
 /* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
 int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
                            int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,

@@ -521,3 +521,60 @@ def test_tree_parts_compute_the_whole_tree_walk():
             assert int((root[:, 0] == 0).sum()) + sum(int((p[:, 0] == 0).sum()) for p in parts) == n_gemm
             seen_cut |= len(parts) > 1
     assert seen_cut
+
+
+def test_clade_tables_compute_the_whole_tree_walk():
+    """Clade tables (subtree site repeats): clades walked once per distinct sub-pattern, the main program gathering their
+    tables, reproduce the whole-tree program on every pattern (numpy emulator); the plan is self-consistent (every pattern's
+    sub-pattern carries its codes, products add up, clades are disjoint and small)."""
+    from crabml_amd.engine import compile_clade_tables, compile_path_program
+    rng = np.random.default_rng(23)
+    n = 5
+    used = 0
+    for trial in range(8):
+        n_leaves = int(rng.integers(6, 40))
+        parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
+        while len(open_nodes) > 1:
+            k = int(min(len(open_nodes), rng.choice([1, 2, 2, 2, 3])))
+            pick = rng.choice(len(open_nodes), size=k, replace=False)
+            for i in sorted(pick, reverse=True):
+                parent[open_nodes.pop(int(i))] = nxt
+            open_nodes.append(nxt)
+            nxt += 1
+        par = np.array([parent.get(v, -1) for v in range(nxt)], dtype=np.int32)
+        leaf = np.arange(n_leaves, dtype=np.int32)
+        n_pat = int(rng.integers(300, 700))
+        base = rng.integers(0, n + 1, size=n_pat)                      # related sequences: sub-patterns repeat (code n = missing)
+        codes = np.stack([np.where(rng.random(n_pat) < 0.15, rng.integers(0, n + 1, size=n_pat), base) for _ in range(n_leaves)]).astype(np.int32)
+        pi = rng.dirichlet(np.ones(n))
+        P = {v: rng.dirichlet(np.ones(n), size=n) for v in range(nxt)}
+        whole, _ = compile_path_program(par, leaf)
+        want = emulate_program(whole, P, codes, pi, n_states=n)
+        main, clades = compile_clade_tables(par, leaf, codes, n_states=n)
+        if not clades:
+            assert np.array_equal(main, whole) or len(main) == len(whole)
+            continue
+        used += 1
+        tables, wide, rows_seen = {}, {}, set()
+        for j, c in enumerate(clades):
+            ops = c["ops"]
+            assert (ops[-1, 0], ops[-1, 2] & (1024 | 2048)) == (3, 1024 | 2048) and ops[-2, 0] == 0 and ops[-2, 1] == c["root"]
+            sub, index = c["sub_codes"], c["index"].astype(np.int64)
+            U = sub.shape[1]
+            assert 1 <= U <= n_pat and index.max() == U - 1 and len(np.unique(index)) == U
+            rows = [int(r) for r in np.unique(ops[ops[:, 0] == 1, 3])]
+            assert 2 <= len(rows) <= 16 and not rows_seen & set(rows)
+            rows_seen |= set(rows)
+            canon = np.where((codes >= 0) & (codes < n), codes, n)
+            assert np.array_equal(sub[rows][:, index], canon[rows])     # every pattern's sub-pattern carries its codes
+            tables[c["root"]] = emulate_program(ops, P, sub, pi, n_states=n)
+            assert tables[c["root"]].shape == (U, n)
+            wide[n_leaves + j] = index
+        table_leaves = main[(main[:, 0] == 1) & (main[:, 3] >= n_leaves)]
+        assert sorted(table_leaves[:, 3]) == list(range(n_leaves, n_leaves + len(clades)))
+        assert sorted(table_leaves[:, 1]) == sorted(c["root"] for c in clades)
+        n_gemm = lambda ops: int((ops[:, 0] == 0).sum())
+        assert n_gemm(main) + sum(n_gemm(c["ops"]) for c in clades) == n_gemm(whole)
+        got = emulate_program(main, P, codes, pi, n_states=n, tables=tables, wide=wide)
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+    assert used >= 4

@@ -58,14 +58,19 @@ OP_LOAD = 3
 F_POP_SAVED, F_SAVE = 512, 1024
 
 
-def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=False):
+F_TABLE = 2048
+
+
+def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=False, tables=None, wide=None):
     """Run the op list exactly as prune_kernel does (minus rescaling, which is exact) and return f[s].
 
     P_of_node[v] is the n x n transition matrix on the branch above node v; codes [n_rows, S].  Ops have 5 fields
     (crab_compile_tree) or 6 (crab_compile_path_program: the sixth is the save slot).  ``save=True`` fills the dict
     ``saved`` the way a base walk with F_SAVE fills the save area (slot sv: operand of each product, sv+1: the parent's
     running product after the op unless it completes the parent, sv+2: the message before a pop); path programs (OP_LOAD,
-    F_POP_SAVED) read it."""
+    F_POP_SAVED) read it.  Clade tables: a clade program ends with OP_LOAD | F_SAVE | F_TABLE, at which the emulator returns
+    the current tile [U, n_states] (the clade's table); in the main program a leaf op whose row is a key of ``wide`` gathers
+    rows wide[row] of tables[node] instead of columns of P."""
     S = codes.shape[1]
     cur = prod = None
     stack = {}
@@ -78,6 +83,10 @@ def emulate_program(ops, P_of_node, codes, pi, n_states=61, saved=None, save=Fal
             t = prod @ P_of_node[node].T          # the current tile: a product always follows its operand's last op
             if save and flags & F_POP_MUL:
                 saved[sv + 2] = t
+        elif kind == OP_LEAF and wide is not None and arg in wide:
+            t = tables[node][wide[arg]]
+        elif kind == OP_LOAD and (flags & (F_SAVE | F_TABLE)) == (F_SAVE | F_TABLE):
+            return prod
         elif kind == OP_LEAF:
             c = codes[arg]
             valid = (c >= 0) & (c < n_states)
