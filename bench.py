@@ -282,7 +282,7 @@ def main():
         # distinct sub-patterns, then the main programs -- and executes fewer products than one per (pattern, internal branch,
         # class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
         # stats average); the nominal count of a whole walk stands beside it.
-        launches = 2 if n_clades > 0 else 1
+        launches = eng.last_prune_launches()
         kernel_ms_step = float(np.mean(prune_ms))
         kernel_ms = kernel_ms_step / launches
         achieved = dense * FLOP_PER_UPDATE / (kernel_ms_step * 1e-3) / 1e12

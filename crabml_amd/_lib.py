@@ -30,6 +30,7 @@ SIGNATURES = {
     "crab_n_devices": (C.c_int, [vp]),
     "crab_set_eigensolver": (C.c_int, [vp, C.c_int]),
     "crab_set_clade_tables": (C.c_int, [vp, C.c_int]),
+    "crab_last_prune_launches": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "crab_last_clade_tables": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "crab_destroy": (None, [vp]),
     "crab_last_error": (C.c_char_p, [vp]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     "crab_compile_path_program": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compile_tree_part": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crab_compile_clade_tables": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int64, C.c_int, C.c_int, ip, C.c_int, C.POINTER(C.c_int),
-                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), ip]),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint32), ip]),
     "crab_compress_patterns": (C.c_int, [ip, C.c_int, C.c_int64, C.c_int, lp, dp, lp, lp]),
     "crab_host_pool_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crab_spectral_decompose": (C.c_int, [C.c_int, dp, dp, dp, dp, dp]),

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -430,12 +431,21 @@ struct TreeParts {
 // once per sub-pattern; the message of its root's branch goes into a table that the main program reads like a leaf edge.
 struct CladeTables {
     bool built = false;              // for the engine's current tree and alignment (an empty set is a valid outcome)
-    std::vector<int> roots;          // clade root nodes in program order; clade j's wide row is alignment row aln_rows + j
-    std::vector<int64_t> U, tiles;   // distinct sub-patterns per clade, and ceil(U / tile width)
-    std::vector<int> slot_off;       // first 64 KiB slot of clade j's table inside one class's run of table slots
+    struct Clade {
+        int root = -1;               // the clade's root node
+        int parent = -1;             // the clade whose program gathers from this one's table, -1: the main program
+        int level = 1;               // 1: no clade inside; a clade's program runs after those of all lower levels
+        int row = 0;                 // its wide row among those of its consumer's launch: alignment row aln_rows + row there
+        int64_t U = 0, tiles = 0;    // distinct sub-patterns, and ceil(U / tile width)
+        int slot_off = 0;            // first 64 KiB slot of its table inside one class's run of table slots
+        PathProgram prog;            // its subtree with inner clades as table leaves, the product on its root's branch, the store
+    };
+    std::vector<Clade> clades;       // by (level, program order)
+    int n_levels = 0;
+    std::vector<int> level_begin;    // clades of level l + 1 are [level_begin[l], level_begin[l + 1])
+    std::vector<int64_t> row_begin;  // wide rows of launch l (levels first, the main program last) are [row_begin[l], row_begin[l + 1])
     int slots_per_class = 0;
-    std::vector<PathProgram> progs;  // per clade: its subtree, the product on its root's branch, the table store
-    PathProgram main;                // the tree with every clade replaced by a table leaf
+    PathProgram main;                // the tree with every outermost clade replaced by a table leaf
 };
 
 struct crab_engine : TreeProgram {
@@ -454,10 +464,16 @@ struct crab_engine : TreeProgram {
     int64_t dev_bounds_first[9] = {0}, dev_bounds_second[9] = {0};   // per-XCD chunks of the two launches' work items
     int dev_part_target = 0;            // the tree-part size the uploaded programs were cut for (0: uncut)
     bool dev_clades = false;            // the uploaded programs are clade programs + main programs
+    struct CladeLaunch {                // one launch of clade programs (one level)
+        int list_off = 0, n_entries = 0;      // its entries of the program list
+        int64_t items_off = 0, n_items = 0;   // its work items
+        int64_t bounds[9] = {0};
+    };
+    std::vector<CladeLaunch> dev_clade_launches;
     int64_t dev_gemm_extra = 0;         // products of the uploaded clade programs, all sub-patterns and classes (not per pattern)
     CladeTables clades;
     bool clade_tables_on = true;        // crab_set_clade_tables
-    int last_n_clades = 0;
+    int last_n_clades = 0, last_n_launches = 1;   // launches of the pruning kernel in the last evaluation
     std::vector<uint8_t> h_codes;       // host copy of d_codes: [aln_rows][n_pat_pad]
     TreeParts tree_parts;
     int64_t dev_gemm_per_pat = 0, dev_leaf_per_pat = 0;
@@ -960,121 +976,191 @@ void build_tree_parts(const TreeProgram *e, int target, TreeParts &tp)
 // distinct sub-patterns than the alignment has patterns (configs[1]: a 6-leaf clade ~15 % of 9 953), and everything the
 // pruning pass computes below the clade's root -- its conditional likelihoods and the message of the branch above it --
 // depends on the sub-pattern only.  Chosen clades are therefore walked once per distinct sub-pattern by programs of their
-// own (launch 1: the clade's subtree ops, the product on its root's branch, a store into the clade's table), and the main
-// program (launch 2) replaces subtree and product by one leaf-style gather from that table, indexed per pattern.
+// own (the clade's subtree ops, the product on its root's branch, a store into the clade's table), and whoever contains the
+// clade -- a larger clade's program, or the main program -- replaces subtree and product by one leaf-style gather from that
+// table, indexed per (sub-)pattern.  Clades nest: level 1 holds none, a clade of level l gathers from clades of lower levels
+// and is walked over ITS distinct sub-patterns; one launch per level, the main programs last.
 // Same ops, same order, same rescaling points as the whole-tree program; a table entry is the tile the whole walk would
 // hold after that product, with its power-of-two exponent folded in (exact), and every later normalisation brings the
 // running product back to the same mantissas: results are bit-identical to whole walks (tests/test_clade_tables.py).
-// Choice: one level (clades do not nest), at most 16 leaves (the folded exponent stays far inside the fp64 range),
-// minimising products: a clade costs (products below + 1) x padded sub-patterns + a gather per pattern, walking a node
-// costs one product per pattern plus the best of its internal children.
-// (host only: `codes` is the byte code table [aln_rows][npp] of the n_pat patterns; idx and alt are the wide rows and the clades'
-// code table to upload)
+// Choice: clades of at most 64 leaves (the folded exponent stays far inside the fp64 range), minimising products by a
+// dynamic programme over (node, number of patterns it is walked for): walking a node costs one product per pattern plus
+// its internal children in the same context; tabling it costs a gather per pattern plus, once, its product and its
+// children over its own padded sub-patterns.
+// (host only: `codes` is the byte code table [aln_rows][npp] of the n_pat patterns; idx holds the wide rows of every launch,
+// alt one code table per level)
 void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows, int64_t n_pat, int64_t npp, int n_states,
                        CladeTables &ct, std::vector<uint32_t> &idx, std::vector<uint8_t> &alt)
 {
     ct = CladeTables{};
     ct.built = true;
+    idx.clear();
+    alt.clear();
     const int nn = e->n_nodes, tile = prune_tile_width();
     if (n_pat < 4 * tile || e->n_gemm_edges < 2) return;
     auto env_num = [](const char *name, double dflt) {
         const char *sv = std::getenv(name);
         return sv && sv[0] ? std::atof(sv) : dflt;
     };
-    // tuning knobs (experiments: scripts/gpu_clade_sweep.sh); the defaults are the measured optimum at configs[1]
-    const int MAX_LEAVES = std::max(2, std::min(16, (int)env_num("CRAB_CLADE_MAX_LEAVES", 16)));
+    // tuning knobs (experiments: scripts/gpu_clade_levels.sh, gpu_clade_sweep2.sh); the defaults are the measured optimum over
+    // configs[1] and the target workload: deeper nesting executes fewer products but adds launches of ever smaller items
+    const int MAX_LEAVES = std::max(2, std::min(64, (int)env_num("CRAB_CLADE_MAX_LEAVES", 64)));
+    const int MAX_LEVELS = std::max(1, std::min(8, (int)env_num("CRAB_CLADE_MAX_LEVELS", 3)));
     const double GATHER_COST = env_num("CRAB_CLADE_GATHER_COST", 0.15);     // a table gather + multiply per pattern, in products
     const double PREPASS_COST = env_num("CRAB_CLADE_PREPASS_COST", 1.0);    // a product of a clade program against one of the main program
-    const double ITEM_COST = env_num("CRAB_CLADE_ITEM_COST", 0.0);          // fixed cost of a clade work item (prologue), in products x patterns of a tile
+    const double ITEM_COST = env_num("CRAB_CLADE_ITEM_COST", 1.0);          // fixed cost of a clade work item (prologue), in products x patterns of a tile
     const std::vector<TreeOp> &ops = e->ops;
+    auto internal_children = [&](int v, std::vector<int> &out) {
+        out.clear();
+        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci)
+            if (!e->in_leaf_set[e->child[ci]]) out.push_back(e->child[ci]);
+    };
     // post-order over the internal nodes = order of their last op
     std::vector<int> internal;
     for (int v = 0; v < nn; ++v)
         if (e->reachable[v] && !e->in_leaf_set[v] && e->op_fin[v] >= 0) internal.push_back(v);
     std::sort(internal.begin(), internal.end(), [&](int a, int b) { return e->op_fin[a] < e->op_fin[b]; });
-    std::vector<std::vector<int>> rows(nn);          // alignment rows below a node (kept only up to MAX_LEAVES)
-    std::vector<int> n_rows(nn, 0), n_prod(nn, 0);
-    std::vector<int64_t> U(nn, -1);
-    std::vector<double> best(nn, 0.0), as_table(nn, -1.0);
-    // distinct sub-patterns of a set of rows: open addressing on a hash of the (<= 16) bytes
+    // ---- distinct sub-patterns of every candidate node, bottom-up: a node's sub-pattern is the tuple of its children's ----
+    std::vector<int> n_rows(nn, 0);
+    std::vector<char> cand(nn, 0);
+    std::vector<std::vector<int32_t>> ids(nn), reps(nn);     // per candidate: sub-pattern of every pattern; first pattern of every sub-pattern
     size_t cap = 64;
     while (cap < (size_t)n_pat * 2) cap <<= 1;
-    std::vector<int32_t> slot_pat(cap), ids;
-    std::vector<int64_t> reps;
-    auto distinct = [&](const std::vector<int> &rr, bool want_ids) -> int64_t {
-        std::fill(slot_pat.begin(), slot_pat.end(), -1);
-        if (want_ids) ids.assign(n_pat, 0), reps.clear();
-        int64_t n_u = 0;
-        const int nr = (int)rr.size();
-        for (int64_t p = 0; p < n_pat; ++p) {
-            uint64_t k0 = 0, k1 = 0;
-            for (int i = 0; i < nr; ++i) {
-                const uint64_t c = codes[(size_t)rr[i] * npp + p];
-                if (i < 8) k0 |= c << (8 * i); else k1 |= c << (8 * (i - 8));
-            }
-            size_t h = (size_t)mix64(mix64(0x51ed270b7a3f11c5ull, k0), k1) & (cap - 1);
-            for (;;) {
-                const int32_t q = slot_pat[h];
-                if (q < 0) {
-                    slot_pat[h] = (int32_t)p;
-                    if (want_ids) ids[p] = (int32_t)n_u, reps.push_back(p);
-                    ++n_u;
-                    break;
-                }
-                bool same = true;
-                for (int i = 0; i < nr && same; ++i) same = codes[(size_t)rr[i] * npp + q] == codes[(size_t)rr[i] * npp + p];
-                if (same) {
-                    if (want_ids) ids[p] = ids[q];
-                    break;
-                }
-                h = (h + 1) & (cap - 1);
-            }
-        }
-        return n_u;
-    };
+    std::vector<int32_t> slot_pat(cap);
+    std::vector<const int32_t *> key_i;                       // the tuple's int components (children that are candidates) ...
+    std::vector<const uint8_t *> key_b;                       // ... and its byte components (leaf children)
     for (int v : internal) {
-        bool small = true;
-        double walk = v == e->root ? 0.0 : (double)n_pat;
+        bool ok = v != e->root;
+        key_i.clear(), key_b.clear();
         for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci) {
             const int c = e->child[ci];
             if (e->in_leaf_set[c]) {
                 n_rows[v] += 1;
-                if (small && (int)rows[v].size() < MAX_LEAVES) rows[v].push_back(e->leaf_row[c]);
+                key_b.push_back(codes + (size_t)e->leaf_row[c] * npp);
             } else {
                 n_rows[v] += n_rows[c];
-                n_prod[v] += n_prod[c] + 1;
-                walk += best[c];
-                if (n_rows[c] > MAX_LEAVES || (U[c] >= 0 && 2 * U[c] > n_pat)) small = false;   // U only grows towards the root
-                if (small) rows[v].insert(rows[v].end(), rows[c].begin(), rows[c].end());
-                std::vector<int>().swap(rows[c]);
+                if (!cand[c] || 2 * (int64_t)reps[c].size() > n_pat) ok = false;   // the count only grows towards the root
+                else key_i.push_back(ids[c].data());
             }
         }
-        best[v] = walk;
-        if (v == e->root || !small || n_rows[v] < 2 || n_rows[v] > MAX_LEAVES) continue;
-        U[v] = distinct(rows[v], false);
-        const int64_t u_pad = (U[v] + tile - 1) / tile * tile;
-        as_table[v] = PREPASS_COST * (double)(n_prod[v] + 1) * (double)u_pad + ITEM_COST * (double)u_pad + GATHER_COST * (double)n_pat;
-        if (as_table[v] < walk) best[v] = as_table[v];
-    }
-    // top-down: the first node on every path from the root that is cheaper as a table
-    std::vector<int> stack{e->root};
-    while (!stack.empty()) {
-        const int v = stack.back();
-        stack.pop_back();
-        if (as_table[v] >= 0.0 && best[v] == as_table[v]) {
-            ct.roots.push_back(v);
-            continue;
+        if (!ok || n_rows[v] < 2 || n_rows[v] > MAX_LEAVES) continue;
+        std::fill(slot_pat.begin(), slot_pat.end(), -1);
+        std::vector<int32_t> &id = ids[v], &rp = reps[v];
+        id.assign(n_pat, 0);
+        for (int64_t p = 0; p < n_pat; ++p) {
+            uint64_t h = 0x51ed270b7a3f11c5ull;
+            for (const int32_t *k : key_i) h = mix64(h, (uint64_t)(uint32_t)k[p]);
+            for (const uint8_t *k : key_b) h = mix64(h, k[p]);
+            size_t at = (size_t)h & (cap - 1);
+            for (;;) {
+                const int32_t q = slot_pat[at];
+                if (q < 0) {
+                    slot_pat[at] = (int32_t)p;
+                    id[p] = (int32_t)rp.size();
+                    rp.push_back((int32_t)p);
+                    break;
+                }
+                bool same = true;
+                for (size_t i = 0; i < key_i.size() && same; ++i) same = key_i[i][q] == key_i[i][p];
+                for (size_t i = 0; i < key_b.size() && same; ++i) same = key_b[i][q] == key_b[i][p];
+                if (same) {
+                    id[p] = id[q];
+                    break;
+                }
+                at = (at + 1) & (cap - 1);
+            }
         }
-        for (int ci = e->child_start[v]; ci < e->child_start[v + 1]; ++ci)
-            if (!e->in_leaf_set[e->child[ci]]) stack.push_back(e->child[ci]);
+        cand[v] = 1;
     }
-    if (ct.roots.empty()) return;
-    std::sort(ct.roots.begin(), ct.roots.end(), [&](int a, int b) { return e->op_begin[a] < e->op_begin[b]; });
-    const int n_cl = (int)ct.roots.size();
-    // per clade: sub-pattern ids per pattern (the wide row), the sub-patterns' codes (the clade's rows of codes_alt)
-    idx.assign((size_t)n_cl * npp, 0u);
-    alt.assign((size_t)aln_rows * npp, (uint8_t)n_states);
-    ct.U.resize(n_cl), ct.tiles.resize(n_cl), ct.slot_off.resize(n_cl), ct.progs.resize(n_cl);
+    auto u_pad = [&](int v) { return ((int64_t)reps[v].size() + tile - 1) / tile * tile; };
+    // ---- the dynamic programme: cost of the subtree below v (its own branch included) when walked for ctx patterns ----
+    struct Choice {
+        double cost;
+        bool table;
+    };
+    std::map<std::pair<int, int64_t>, Choice> memo;
+    std::vector<double> table_cost(nn, -1.0);
+    std::vector<int> depth_left(nn, 0);
+    std::function<Choice(int, int64_t, int)> cost = [&](int v, int64_t ctx, int levels_left) -> Choice {
+        const auto key = std::make_pair(v, ctx * 16 + levels_left);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        std::vector<int> ic;
+        internal_children(v, ic);
+        double walk = (double)ctx;
+        for (int c : ic) walk += cost(c, ctx, levels_left).cost;
+        Choice out{walk, false};
+        if (cand[v] && levels_left > 0) {
+            const int64_t up = u_pad(v);
+            double t = PREPASS_COST * (double)up + ITEM_COST * (double)up;
+            for (int c : ic) t += PREPASS_COST * cost(c, up, levels_left - 1).cost;
+            t += GATHER_COST * (double)ctx;
+            if (t < walk) out = Choice{t, true};
+        }
+        memo.emplace(key, out);
+        return out;
+    };
+    // ---- extract the chosen clades, outermost first ----
+    struct Pick {
+        int v, parent;
+        int64_t ctx;
+        int levels_left;
+    };
+    std::vector<Pick> todo;
+    {
+        std::vector<int> ic;
+        internal_children(e->root, ic);
+        for (int c : ic) todo.push_back({c, -1, n_pat, MAX_LEVELS});
+    }
+    std::vector<CladeTables::Clade> found;
+    while (!todo.empty()) {
+        const Pick pk = todo.back();
+        todo.pop_back();
+        const Choice ch = cost(pk.v, pk.ctx, pk.levels_left);
+        std::vector<int> ic;
+        internal_children(pk.v, ic);
+        if (ch.table) {
+            CladeTables::Clade cl;
+            cl.root = pk.v;
+            cl.parent = pk.parent;
+            cl.U = (int64_t)reps[pk.v].size();
+            cl.tiles = (cl.U + tile - 1) / tile;
+            found.push_back(std::move(cl));
+            const int me = (int)found.size() - 1;
+            for (int c : ic) todo.push_back({c, me, u_pad(pk.v), pk.levels_left - 1});
+        } else {
+            for (int c : ic) todo.push_back({c, pk.parent, pk.ctx, pk.levels_left});
+        }
+    }
+    if (found.empty()) return;
+    // levels bottom-up (children were found after their parents)
+    for (int i = (int)found.size() - 1; i >= 0; --i)
+        if (found[i].parent >= 0) found[found[i].parent].level = std::max(found[found[i].parent].level, found[i].level + 1);
+    std::vector<int> order(found.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return found[a].level != found[b].level ? found[a].level < found[b].level : e->op_begin[found[a].root] < e->op_begin[found[b].root];
+    });
+    std::vector<int> new_index(found.size());
+    for (size_t i = 0; i < order.size(); ++i) new_index[order[i]] = (int)i;
+    ct.clades.resize(found.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        ct.clades[i] = std::move(found[order[i]]);
+        if (ct.clades[i].parent >= 0) ct.clades[i].parent = new_index[ct.clades[i].parent];
+    }
+    const int n_cl = (int)ct.clades.size();
+    ct.n_levels = ct.clades.back().level;
+    ct.level_begin.assign(ct.n_levels + 1, n_cl);
+    for (int i = n_cl - 1; i >= 0; --i) ct.level_begin[ct.clades[i].level - 1] = i;
+    ct.level_begin[ct.n_levels] = n_cl;
+    // wide rows: launch l < n_levels serves the clades of level l + 1, launch n_levels the main program
+    auto launch_of_consumer = [&](int parent) { return parent < 0 ? ct.n_levels : ct.clades[parent].level - 1; };
+    std::vector<int64_t> rows_in(ct.n_levels + 1, 0);
+    for (auto &cl : ct.clades) cl.row = (int)rows_in[launch_of_consumer(cl.parent)]++;
+    ct.row_begin.assign(ct.n_levels + 2, 0);
+    for (int l = 0; l <= ct.n_levels; ++l) ct.row_begin[l + 1] = ct.row_begin[l] + rows_in[l];
+    idx.assign((size_t)ct.row_begin[ct.n_levels + 1] * npp, 0u);
+    alt.assign((size_t)ct.n_levels * aln_rows * npp, (uint8_t)n_states);
     auto rows_below = [&](int c) {
         std::vector<int> rr, st{c};
         while (!st.empty()) {
@@ -1090,62 +1176,79 @@ void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows,
     };
     int slot = 0;
     for (int j = 0; j < n_cl; ++j) {
-        const int c = ct.roots[j];
-        const std::vector<int> rr = rows_below(c);
-        ct.U[j] = distinct(rr, true);
-        ct.tiles[j] = (ct.U[j] + tile - 1) / tile;
-        for (int64_t p = 0; p < n_pat; ++p) idx[(size_t)j * npp + p] = (uint32_t)ids[p];
-        for (int r : rr)
-            for (int64_t u = 0; u < ct.U[j]; ++u) alt[(size_t)r * npp + u] = codes[(size_t)r * npp + reps[u]];
+        CladeTables::Clade &cl = ct.clades[j];
+        // where its consumer looks it up: per pattern (main program) or per distinct sub-pattern of the consuming clade
+        uint32_t *row = idx.data() + (size_t)(ct.row_begin[launch_of_consumer(cl.parent)] + cl.row) * npp;
+        if (cl.parent < 0) {
+            for (int64_t p = 0; p < n_pat; ++p) row[p] = (uint32_t)ids[cl.root][p];
+        } else {
+            const std::vector<int32_t> &prep = reps[ct.clades[cl.parent].root];
+            for (size_t u = 0; u < prep.size(); ++u) row[u] = (uint32_t)ids[cl.root][prep[u]];
+        }
+        // the codes its own program reads: its distinct sub-patterns on the rows below it
+        uint8_t *lvl = alt.data() + (size_t)(cl.level - 1) * aln_rows * npp;
+        const std::vector<int32_t> &rp = reps[cl.root];
+        for (int r : rows_below(cl.root))
+            for (size_t u = 0; u < rp.size(); ++u) lvl[(size_t)r * npp + u] = codes[(size_t)r * npp + rp[u]];
         // a table is addressed like the gather image of a (pseudo) matrix: it starts half a slot in and runs on
-        ct.slot_off[j] = slot;
-        slot += (int)((P_IMAGE * sizeof(double) + (size_t)ct.tiles[j] * tile * 512 + P_ELEMS * sizeof(double) - 1) / (P_ELEMS * sizeof(double)));
+        cl.slot_off = slot;
+        slot += (int)((P_IMAGE * sizeof(double) + (size_t)cl.tiles * tile * 512 + P_ELEMS * sizeof(double) - 1) / (P_ELEMS * sizeof(double)));
     }
     ct.slots_per_class = slot;
-    // programs
+    // ---- programs: a slice of the whole-tree program with the consumer's own clades replaced by table leaves ----
     auto plain = [&](int i) {
         TreeOp o = ops[i];
         o.flags &= ~(F_PRE_EARLY | F_PRE_LATE | F_PRE_DYING | F_IN_LANDING);
         o.pre_node = o.pre_node_b = o.pre_row2 = o.pre_row3 = -1;
         return o;
     };
-    size_t next = 0;
-    for (int i = 0; i < (int)ops.size();) {
-        if (next < ct.roots.size() && i == e->op_begin[ct.roots[next]]) {
-            const int c = ct.roots[next], gi = e->gemm_op_of[c];
-            PathProgram &pp = ct.progs[next];
-            for (int k = e->op_begin[c]; k <= e->op_fin[c]; ++k) pp.ops.push_back(plain(k));
-            TreeOp g = plain(gi);                 // the message of the branch above the clade: P_c L_c, nothing else
-            g.flags = 0;
-            g.slot = 0;
-            pp.ops.push_back(g);
-            TreeOp st{};
-            st.kind = OP_LOAD;
-            st.node = -1;
-            st.flags = F_SAVE | F_TABLE;
-            st.arg = (int)next;
-            st.pre_node = st.pre_node_b = st.pre_row2 = st.pre_row3 = -1;
-            pp.ops.push_back(st);
-            finalise_program(pp.ops, pp.info);
-            // the main program: the table stands where the product stood -- multiplied into the parent's running product if
-            // the product popped one (then nothing needs the push that saved it), with the product's rescale / push / last-term flags
-            const TreeOp &gw = ops[gi];
-            TreeOp leaf{};
-            leaf.kind = OP_LEAF;
-            leaf.node = c;
-            leaf.arg = aln_rows + (int)next;
-            leaf.flags = (gw.flags & (F_RESCALE | F_FIN | F_PUSH)) | ((gw.flags & F_POP_MUL) ? F_MUL_PROD : 0);
-            leaf.slot = gw.slot;
-            leaf.pre_node = leaf.pre_node_b = leaf.pre_row2 = leaf.pre_row3 = -1;
-            if ((gw.flags & F_POP_MUL) && !ct.main.ops.empty()) ct.main.ops.back().flags &= ~F_PUSH;
-            ct.main.ops.push_back(leaf);
-            i = gi + 1;
-            ++next;
-        } else {
-            ct.main.ops.push_back(plain(i));
-            ++i;
+    std::vector<int> clade_at(ops.size(), -1);          // op index where a clade's subtree begins -> clade
+    for (int j = 0; j < n_cl; ++j) clade_at[e->op_begin[ct.clades[j].root]] = -1;   // (filled per consumer below)
+    auto rewrite = [&](int lo, int hi, int consumer, std::vector<TreeOp> &out) {
+        for (int j = 0; j < n_cl; ++j)
+            if (ct.clades[j].parent == consumer) clade_at[e->op_begin[ct.clades[j].root]] = j;
+        for (int i = lo; i <= hi;) {
+            const int j = clade_at[i];
+            if (j >= 0) {
+                // the table stands where the product stood -- multiplied into the parent's running product if the product
+                // popped one (then nothing needs the push that saved it), with the product's rescale / push / last-term flags
+                const int c = ct.clades[j].root, gi = e->gemm_op_of[c];
+                const TreeOp &gw = ops[gi];
+                TreeOp leaf{};
+                leaf.kind = OP_LEAF;
+                leaf.node = c;
+                leaf.arg = aln_rows + ct.clades[j].row;
+                leaf.flags = (gw.flags & (F_RESCALE | F_FIN | F_PUSH)) | ((gw.flags & F_POP_MUL) ? F_MUL_PROD : 0);
+                leaf.slot = gw.slot;
+                leaf.pre_node = leaf.pre_node_b = leaf.pre_row2 = leaf.pre_row3 = -1;
+                if ((gw.flags & F_POP_MUL) && !out.empty()) out.back().flags &= ~F_PUSH;
+                out.push_back(leaf);
+                i = gi + 1;
+            } else {
+                out.push_back(plain(i));
+                ++i;
+            }
         }
+        for (int j = 0; j < n_cl; ++j)
+            if (ct.clades[j].parent == consumer) clade_at[e->op_begin[ct.clades[j].root]] = -1;
+    };
+    for (int j = 0; j < n_cl; ++j) {
+        CladeTables::Clade &cl = ct.clades[j];
+        rewrite(e->op_begin[cl.root], e->op_fin[cl.root], j, cl.prog.ops);
+        TreeOp g = plain(e->gemm_op_of[cl.root]);     // the message of the branch above the clade: P_c L_c, nothing else
+        g.flags = 0;
+        g.slot = 0;
+        cl.prog.ops.push_back(g);
+        TreeOp st{};
+        st.kind = OP_LOAD;
+        st.node = -1;
+        st.flags = F_SAVE | F_TABLE;
+        st.arg = j;
+        st.pre_node = st.pre_node_b = st.pre_row2 = st.pre_row3 = -1;
+        cl.prog.ops.push_back(st);
+        finalise_program(cl.prog.ops, cl.prog.info);
     }
+    rewrite(0, (int)ops.size() - 1, -1, ct.main.ops);
     finalise_program(ct.main.ops, ct.main.info);
 }
 
@@ -1159,7 +1262,7 @@ void build_clade_tables(crab_engine *e)
         return;
     }
     plan_clade_tables(e, e->h_codes.data(), e->aln_rows, e->n_pat, e->n_pat_pad, e->n_states, e->clades, idx, alt);
-    if (e->clades.roots.empty()) return;
+    if (e->clades.clades.empty()) return;
     HIP_CHECK(hipSetDevice(e->device));
     e->d_idx32.ensure(idx.size());
     e->d_codes_alt.ensure(alt.size());
@@ -1661,9 +1764,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     bool use_clades = false;
     if (G == 1 && prune_supports_paths() && e->clade_tables_on && !clade_tables_disabled() && e->n_pat > 0) {
         if (!e->clades.built) build_clade_tables(e);
-        use_clades = !e->clades.roots.empty();
+        use_clades = !e->clades.clades.empty();
     }
-    const int n_cl = use_clades ? (int)e->clades.roots.size() : 0;
+    const int n_cl = use_clades ? (int)e->clades.clades.size() : 0;
     int part_target = 0;
     if (G == 1 && !use_clades && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
         const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device), n_work = n_tiles * pl.K;
@@ -1721,53 +1824,68 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         std::vector<int32_t> items;                 // launch 1 of clade tables: (list entry, tile) per work item
         if (use_clades) {
             const CladeTables &ct = e->clades;
-            std::vector<int32_t> pk_main(nn);
+            // a program sees the tables it gathers from as the matrices of the clade roots: one patched node -> matrix table per
+            // consumer (a clade, or the main program) and class
+            std::vector<int32_t> pk_c(nn);
+            auto table_mat = [&](int k, int j) { return (int32_t)(M + k * ct.slots_per_class + ct.clades[j].slot_off); };
             for (int k = 0; k < pl.K; ++k) {
                 const int32_t *pk = pidx->data() + (size_t)k * nn;
-                std::copy(pk, pk + nn, pk_main.begin());
-                for (int j = 0; j < n_cl; ++j) {
-                    const int32_t table_mat = M + k * ct.slots_per_class + ct.slot_off[j];
-                    pk_main[ct.roots[j]] = table_mat;           // the main program gathers from the table as from a leaf edge's image
-                    const int prog = pl.K + k * n_cl + j;
-                    DevOp *po = progs.data() + (size_t)prog * prog_stride;
-                    resolve_program(ct.progs[j].ops, pk, false, po);
-                    po[ct.progs[j].ops.size() - 1].mat = table_mat;   // the table store
-                    header(prog, ct.progs[j].info, k, 1);
-                    hdrs[prog].alt_codes = 1;
-                }
-                resolve_program(ct.main.ops, pk_main.data(), false, progs.data() + (size_t)k * prog_stride);
-                header(k, ct.main.info, k, 0);
-            }
-            // launch 1: class-major (one class's matrices stay together), clades with most products first
-            std::vector<int> order(n_cl);
-            for (int j = 0; j < n_cl; ++j) order[j] = j;
-            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return ct.progs[x].info.n_gemm > ct.progs[y].info.n_gemm; });
-            std::vector<double> item_w;
-            for (int k = 0; k < pl.K; ++k)
-                for (int j : order) {
-                    const int entry = (int)lists.size();
-                    lists.push_back(pl.K + k * n_cl + j);
-                    const ProgInfo &in = ct.progs[j].info;
-                    for (int64_t t = 0; t < ct.tiles[j]; ++t) {
-                        items.push_back(entry);
-                        items.push_back((int32_t)t);
-                        item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
+                for (int consumer = -1; consumer < n_cl; ++consumer) {
+                    std::copy(pk, pk + nn, pk_c.begin());
+                    for (int j = 0; j < n_cl; ++j)
+                        if (ct.clades[j].parent == consumer) pk_c[ct.clades[j].root] = table_mat(k, j);
+                    if (consumer < 0) {
+                        resolve_program(ct.main.ops, pk_c.data(), false, progs.data() + (size_t)k * prog_stride);
+                        header(k, ct.main.info, k, 0);
+                    } else {
+                        const PathProgram &pp = ct.clades[consumer].prog;
+                        const int prog = pl.K + k * n_cl + consumer;
+                        DevOp *po = progs.data() + (size_t)prog * prog_stride;
+                        resolve_program(pp.ops, pk_c.data(), false, po);
+                        po[pp.ops.size() - 1].mat = table_mat(k, consumer);   // the table store
+                        header(prog, pp.info, k, 1);
+                        hdrs[prog].alt_codes = 1;
                     }
-                    e->dev_gemm_extra += (int64_t)in.n_gemm * ct.tiles[j] * prune_tile_width();
                 }
-            n_first = (int)lists.size();
-            for (int k = 0; k < pl.K; ++k) lists.push_back(k);
-            {   // one chunk of launch 1's items per XCD, of equal work
+            }
+            // one launch per level: class-major (one class's matrices stay together), clades with most products first
+            e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
+            for (int l = 0; l < ct.n_levels; ++l) {
+                crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+                cl.list_off = (int)lists.size();
+                cl.items_off = (int64_t)items.size() / 2;
+                std::vector<int> order;
+                for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
+                std::stable_sort(order.begin(), order.end(),
+                                 [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
+                std::vector<double> item_w;
+                for (int k = 0; k < pl.K; ++k)
+                    for (int j : order) {
+                        const int entry = (int)lists.size() - cl.list_off;
+                        lists.push_back(pl.K + k * n_cl + j);
+                        const ProgInfo &in = ct.clades[j].prog.info;
+                        for (int64_t t = 0; t < ct.clades[j].tiles; ++t) {
+                            items.push_back(entry);
+                            items.push_back((int32_t)t);
+                            item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
+                        }
+                        e->dev_gemm_extra += (int64_t)in.n_gemm * ct.clades[j].tiles * prune_tile_width();
+                    }
+                cl.n_entries = (int)lists.size() - cl.list_off;
+                cl.n_items = (int64_t)item_w.size();
+                // one chunk of the launch's items per XCD, of equal work
                 double total = 0.0, acc = 0.0;
                 for (double w : item_w) total += w;
                 int x = 1;
-                e->dev_bounds_first[0] = 0;
+                cl.bounds[0] = 0;
                 for (size_t i = 0; i < item_w.size() && x < 8; ++i) {
                     acc += item_w[i];
-                    while (x < 8 && acc >= total * x / 8.0) e->dev_bounds_first[x++] = (int64_t)i + 1;
+                    while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
                 }
-                while (x <= 8) e->dev_bounds_first[x++] = (int64_t)item_w.size();
+                while (x <= 8) cl.bounds[x++] = (int64_t)item_w.size();
             }
+            n_first = (int)lists.size();
+            for (int k = 0; k < pl.K; ++k) lists.push_back(k);
             e->dev_gemm_per_pat = (int64_t)pl.K * ct.main.info.n_gemm;
             e->dev_leaf_per_pat = (int64_t)pl.K * ct.main.info.n_leaf;
         } else if (n_parts > 0) {
@@ -1892,7 +2010,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     int64_t n_items_first = n_tiles * n_first;
     if (use_clades) {
         n_items_first = 0;
-        for (int64_t t : e->clades.tiles) n_items_first += t * pl.K;
+        for (const auto &cl : e->dev_clade_launches) n_items_first = std::max(n_items_first, cl.n_items);
     }
     const int grid = prune_grid_size(n_items_first, e->device);
     const int grid_second = two_launches ? prune_grid_size(n_tiles * n_second, e->device) : 0;
@@ -1943,14 +2061,24 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.first_leaf_op = e->first_leaf_op;
     pa.second_leaf_row = e->second_leaf_row;
     pa.third_leaf_row = e->third_leaf_row;
-    if (use_clades) {     // launch 1: the clade programs, over each clade's distinct sub-patterns
-        pa.items = e->d_items.p;
-        pa.n_items = n_items_first;
-        pa.codes_alt = e->d_codes_alt.p;
-        pa.save = nullptr;
-    }
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
-    launch_prune(pa, grid, e->stream);
+    if (use_clades) {     // one launch per level: the clade programs, over each clade's distinct sub-patterns
+        pa.save = nullptr;
+        pa.n_code_rows = e->aln_rows;
+        for (size_t l = 0; l < e->dev_clade_launches.size(); ++l) {
+            const crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+            pa.K = cl.n_entries;
+            pa.cls_list = e->d_cls.p + cl.list_off;
+            pa.items = e->d_items.p + 2 * cl.items_off;
+            pa.n_items = cl.n_items;
+            pa.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
+            pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
+            std::copy(cl.bounds, cl.bounds + 9, pa.xcd_bounds);
+            launch_prune(pa, prune_grid_size(cl.n_items, e->device), e->stream);
+        }
+    } else {
+        launch_prune(pa, grid, e->stream);
+    }
     if (two_launches) {   // path programs / root programs / main programs read what the first launch left: same stream, after it
         pa.K = n_second;
         pa.cls_list = e->d_cls.p + n_first;
@@ -1958,7 +2086,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         if (use_clades) {
             pa.items = nullptr;
             pa.n_items = 0;
-            pa.idx32 = e->d_idx32.p;
+            pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
             pa.n_code_rows = e->aln_rows;
         }
         launch_prune(pa, grid_second, e->stream);
@@ -2092,6 +2220,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_n_path = (n_parts > 0 || use_clades) ? 0 : n_second / std::max(1, Kg);
     e->last_n_parts = n_parts;
     e->last_n_clades = n_cl;
+    e->last_n_launches = use_clades ? (int)e->dev_clade_launches.size() + 1 : (two_launches ? 2 : 1);
 
     if (pl.post_weights) {
         const double *src = e->h_out.p + G;
@@ -2355,6 +2484,13 @@ int crab_set_clade_tables(crab_engine *e, int on)
     return CRAB_OK;
 }
 
+int crab_last_prune_launches(const crab_engine *e, int *n_launches)
+{
+    if (!e || !n_launches) return CRAB_ERR_ARG;
+    *n_launches = e->is_multi() ? e->shards[0]->last_n_launches : e->last_n_launches;
+    return CRAB_OK;
+}
+
 int crab_last_clade_tables(const crab_engine *e, int *n_clades, int64_t *sub_patterns)
 {
     if (!e) return CRAB_ERR_ARG;
@@ -2363,7 +2499,7 @@ int crab_last_clade_tables(const crab_engine *e, int *n_clades, int64_t *sub_pat
     auto add = [&](const crab_engine *x) {
         n += x->last_n_clades;
         if (x->last_n_clades > 0)
-            for (int64_t v : x->clades.U) u += v;
+            for (const auto &cl : x->clades.clades) u += cl.U;
     };
     if (e->is_multi())
         for (const crab_engine *sh : e->shards) add(sh);
@@ -2838,8 +2974,8 @@ int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *
 
 int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
                               const int32_t *codes, int64_t n_patterns, int n_states, int part, int32_t *ops_out, int ops_capacity,
-                              int *n_ops, int *n_clades, int *clade_root, int64_t *n_sub_patterns, uint32_t *index_out,
-                              int32_t *sub_codes_out)
+                              int *n_ops, int *n_clades, int *clade_root, int *parent_clade, int *wide_row, int64_t *n_sub_patterns,
+                              uint32_t *index_out, int32_t *sub_codes_out)
 {
     return guarded(nullptr, [&] {
         if (!codes || n_patterns < 1 || n_states < 1 || n_states > NS - 1) fail(CRAB_ERR_ARG, "crab_compile_clade_tables: bad arguments");
@@ -2857,10 +2993,10 @@ int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_
         std::vector<uint32_t> idx;
         std::vector<uint8_t> alt;
         plan_clade_tables(&tp, img.data(), n_leaves, n_patterns, npp, n_states, ct, idx, alt);
-        const int n_cl = (int)ct.roots.size();
+        const int n_cl = (int)ct.clades.size();
         if (n_clades) *n_clades = n_cl;
         if (part >= n_cl) fail(CRAB_ERR_ARG, "crab_compile_clade_tables: no such clade");
-        const std::vector<TreeOp> &ops = part < 0 ? ct.main.ops : ct.progs[part].ops;
+        const std::vector<TreeOp> &ops = part < 0 ? ct.main.ops : ct.clades[part].prog.ops;
         if (n_ops) *n_ops = (int)ops.size();
         if (ops_out) {
             if ((int)ops.size() > ops_capacity) fail(CRAB_ERR_ARG, "ops_capacity too small");
@@ -2871,13 +3007,22 @@ int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_
             }
         }
         if (part >= 0) {
-            if (clade_root) *clade_root = ct.roots[part];
-            if (n_sub_patterns) *n_sub_patterns = ct.U[part];
-            if (index_out)
-                for (int64_t p = 0; p < n_patterns; ++p) index_out[p] = idx[(size_t)part * npp + p];
-            if (sub_codes_out)   // [n_leaves][U]: the codes of the clade's distinct sub-patterns on its own rows, n_states elsewhere
+            const CladeTables::Clade &cl = ct.clades[part];
+            if (clade_root) *clade_root = cl.root;
+            if (parent_clade) *parent_clade = cl.parent;
+            if (wide_row) *wide_row = cl.row;
+            if (n_sub_patterns) *n_sub_patterns = cl.U;
+            if (index_out) {   // per pattern (consumer: the main program) or per distinct sub-pattern of the consuming clade
+                const int launch = cl.parent < 0 ? ct.n_levels : ct.clades[cl.parent].level - 1;
+                const int64_t n = cl.parent < 0 ? n_patterns : ct.clades[cl.parent].U;
+                const uint32_t *row = idx.data() + (size_t)(ct.row_begin[launch] + cl.row) * npp;
+                for (int64_t p = 0; p < n; ++p) index_out[p] = row[p];
+            }
+            if (sub_codes_out) {   // [n_leaves][U]: the codes of the clade's distinct sub-patterns on its own rows, n_states elsewhere
+                const uint8_t *lvl = alt.data() + (size_t)(cl.level - 1) * n_leaves * npp;
                 for (int r = 0; r < n_leaves; ++r)
-                    for (int64_t u = 0; u < ct.U[part]; ++u) sub_codes_out[(size_t)r * ct.U[part] + u] = alt[(size_t)r * npp + u];
+                    for (int64_t u = 0; u < cl.U; ++u) sub_codes_out[(size_t)r * cl.U + u] = lvl[(size_t)r * npp + u];
+            }
         }
     });
 }

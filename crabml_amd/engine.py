@@ -335,6 +335,12 @@ class Engine:
         self._check(self._lib.crab_last_clade_tables(self._h, C.byref(n), C.byref(u)))
         return n.value, u.value
 
+    def last_prune_launches(self) -> int:
+        """Launches of the pruning kernel in the last evaluation (crab_last_prune_launches)."""
+        n = C.c_int()
+        self._check(self._lib.crab_last_prune_launches(self._h, C.byref(n)))
+        return n.value
+
     def last_partial_updates(self) -> int:
         """Vectors of the last batched evaluation that re-walked only a branch-to-root path (crab_last_partial_updates)."""
         n = C.c_int()
@@ -415,9 +421,10 @@ def compile_tree_parts(parents, leaf_node_ids, target, node_ids=None):
 
 
 def compile_clade_tables(parents, leaf_node_ids, codes, n_states=61, node_ids=None):
-    """Clade tables as programs (crab_compile_clade_tables; host only): (main program, [clade dicts]) for the patterns in
-    ``codes`` [n_leaves, n_patterns]; a clade dict holds its ``ops`` (int32 [n_ops, 6]), ``root`` node, ``index`` (sub-pattern
-    of every pattern) and ``sub_codes`` ([n_leaves, U])."""
+    """Clade tables as programs (crab_compile_clade_tables; host only): (main program, [clade dicts], inner clades first) for
+    the patterns in ``codes`` [n_leaves, n_patterns]; a clade dict holds its ``ops`` (int32 [n_ops, 6]), ``root`` node,
+    ``parent`` clade (-1: the main program), ``row`` (its wide row in its consumer's programs), ``index`` (its sub-pattern for
+    every pattern of its consumer) and ``sub_codes`` ([n_leaves, U])."""
     lib = L.load()
     par, parp = L.i32(parents)
     leaf, leafp = L.i32(leaf_node_ids)
@@ -428,16 +435,17 @@ def compile_clade_tables(parents, leaf_node_ids, codes, n_states=61, node_ids=No
     n_leaves, n_pat = cod.shape
 
     def one(part):
-        n_ops, n_cl, root, U = C.c_int(), C.c_int(), C.c_int(-1), C.c_int64(0)
+        n_ops, n_cl, root, parent, row, U = C.c_int(), C.c_int(), C.c_int(-1), C.c_int(-1), C.c_int(0), C.c_int64(0)
         args = (len(par), idp, parp, leafp, len(leaf), codp, n_pat, int(n_states), part)
-        L.check(lib.crab_compile_clade_tables(*args, None, 0, C.byref(n_ops), C.byref(n_cl), C.byref(root), C.byref(U), None, None))
+        refs = (C.byref(n_ops), C.byref(n_cl), C.byref(root), C.byref(parent), C.byref(row), C.byref(U))
+        L.check(lib.crab_compile_clade_tables(*args, None, 0, *refs, None, None))
         ops = np.zeros((n_ops.value, 6), dtype=np.int32)
         index = np.zeros(n_pat, dtype=np.uint32)
         sub = np.zeros((n_leaves, max(1, U.value)), dtype=np.int32)
-        L.check(lib.crab_compile_clade_tables(*args, ops.ctypes.data_as(L.ip), n_ops.value, C.byref(n_ops), C.byref(n_cl), C.byref(root),
-                                              C.byref(U), index.ctypes.data_as(C.POINTER(C.c_uint32)) if part >= 0 else None,
+        L.check(lib.crab_compile_clade_tables(*args, ops.ctypes.data_as(L.ip), n_ops.value, *refs,
+                                              index.ctypes.data_as(C.POINTER(C.c_uint32)) if part >= 0 else None,
                                               sub.ctypes.data_as(L.ip) if part >= 0 else None))
-        return ops, n_cl.value, dict(ops=ops, root=root.value, index=index, sub_codes=sub[:, : U.value])
+        return ops, n_cl.value, dict(ops=ops, root=root.value, parent=parent.value, row=row.value, index=index, sub_codes=sub[:, : U.value])
 
     main, n_cl, _ = one(-1)
     return main, [one(j)[2] for j in range(n_cl)]

@@ -85,12 +85,15 @@ int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
 int crab_set_eigensolver(crab_engine *e, int on_device);
 /* Clade tables (subtree site repeats; on by default, CRAB_NO_CLADE_TABLES=1 switches them off for every engine).  The reference
  * computes every column at every node (likelihood.rs:176-195).  A single evaluation (one parameter vector) instead walks each
- * chosen clade -- a subtree of at most 16 leaves whose leaves show few distinct sub-patterns -- once per distinct sub-pattern
- * and lets the rest of the tree gather the clade's message per pattern; bit-identical to whole walks, a multiple fewer
+ * chosen clade -- a subtree of at most 64 leaves whose leaves show few distinct sub-patterns; clades nest -- once per distinct
+ * sub-pattern and lets whatever contains it gather the clade's message per (sub-)pattern; bit-identical to whole walks, a multiple fewer
  * products on alignments of related sequences.  crab_last_clade_tables: clades used by the last evaluation (0: whole walks)
  * and the sum of their distinct sub-pattern counts (over the shards of a multi-device handle). */
 int crab_set_clade_tables(crab_engine *e, int on);
 int crab_last_clade_tables(const crab_engine *e, int *n_clades, int64_t *sub_patterns);
+/* Launches of the pruning kernel in the last evaluation: 1 (whole walks), 2 (partial updates, tree parts), or one per clade level
+ * plus one (what a profiler's per-kernel average divides by). */
+int crab_last_prune_launches(const crab_engine *e, int *n_launches);
 /* Shards behind a handle: 1 for crab_create, n_devices for crab_create_multi. */
 int crab_n_devices(const crab_engine *e);
 void crab_destroy(crab_engine *e);
@@ -277,14 +280,16 @@ int crab_compile_path_program(int n_nodes, const int32_t *node_ids, const int32_
 int crab_compile_tree_part(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
                            int target, int part, int32_t *ops_out, int ops_capacity, int *n_ops, int *n_parts);
 /* Clade tables as programs, for tests (no device needed; `codes` holds the patterns as given, [n_leaves][n_patterns]).  part = -1:
- * the main program, in which each chosen clade is one leaf-edge op whose alignment row is n_leaves + clade index; part = j >= 0:
- * clade j's program (its subtree, the product on its root's branch, a store with flags F_SAVE | F_TABLE), with its root node,
- * its number of distinct sub-patterns U, the sub-pattern index of every pattern (index_out[n_patterns]) and the sub-patterns'
- * codes (sub_codes_out [n_leaves][U], n_states on rows outside the clade).  Ops as in crab_compile_tree_part. */
+ * the main program, in which each outermost clade is one leaf-edge op whose alignment row is n_leaves + its wide row; part = j >= 0
+ * (clades come by level, inner ones first): clade j's program (its subtree with the clades inside it as such leaf-edge ops, the
+ * product on its root's branch, a store with flags F_SAVE | F_TABLE), its root node, the clade that gathers from it
+ * (parent_clade, -1: the main program), its wide row there, its number of distinct sub-patterns U, its index for every pattern
+ * of its consumer (index_out: n_patterns entries for the main program, U of the parent clade otherwise; capacity n_patterns) and
+ * its sub-patterns' codes (sub_codes_out [n_leaves][U], n_states on rows outside the clade).  Ops as in crab_compile_tree_part. */
 int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
                               const int32_t *codes, int64_t n_patterns, int n_states, int part, int32_t *ops_out, int ops_capacity,
-                              int *n_ops, int *n_clades, int *clade_root, int64_t *n_sub_patterns, uint32_t *index_out,
-                              int32_t *sub_codes_out);
+                              int *n_ops, int *n_clades, int *clade_root, int *parent_clade, int *wide_row, int64_t *n_sub_patterns,
+                              uint32_t *index_out, int32_t *sub_codes_out);
 /* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
 int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
                            int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,

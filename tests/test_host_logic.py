@@ -530,7 +530,7 @@ def test_clade_tables_compute_the_whole_tree_walk():
     from crabml_amd.engine import compile_clade_tables, compile_path_program
     rng = np.random.default_rng(23)
     n = 5
-    used = 0
+    used = seen_nested = 0
     for trial in range(8):
         n_leaves = int(rng.integers(6, 40))
         parent, open_nodes, nxt = {}, list(range(n_leaves)), n_leaves
@@ -555,26 +555,31 @@ def test_clade_tables_compute_the_whole_tree_walk():
             assert np.array_equal(main, whole) or len(main) == len(whole)
             continue
         used += 1
-        tables, wide, rows_seen = {}, {}, set()
+        tables, nested = {}, 0
+        n_sub = [c["sub_codes"].shape[1] for c in clades]
+        canon = np.where((codes >= 0) & (codes < n), codes, n)
         for j, c in enumerate(clades):
             ops = c["ops"]
             assert (ops[-1, 0], ops[-1, 2] & (1024 | 2048)) == (3, 1024 | 2048) and ops[-2, 0] == 0 and ops[-2, 1] == c["root"]
-            sub, index = c["sub_codes"], c["index"].astype(np.int64)
-            U = sub.shape[1]
+            assert c["parent"] == -1 or c["parent"] > j                  # inner clades come first
+            sub, U = c["sub_codes"], n_sub[j]
+            n_consumer = n_pat if c["parent"] < 0 else n_sub[c["parent"]]
+            index = c["index"][:n_consumer].astype(np.int64)
             assert 1 <= U <= n_pat and index.max() == U - 1 and len(np.unique(index)) == U
-            rows = [int(r) for r in np.unique(ops[ops[:, 0] == 1, 3])]
-            assert 2 <= len(rows) <= 16 and not rows_seen & set(rows)
-            rows_seen |= set(rows)
-            canon = np.where((codes >= 0) & (codes < n), codes, n)
-            assert np.array_equal(sub[rows][:, index], canon[rows])     # every pattern's sub-pattern carries its codes
-            tables[c["root"]] = emulate_program(ops, P, sub, pi, n_states=n)
+            rows = [int(r) for r in np.unique(ops[(ops[:, 0] == 1) & (ops[:, 3] < n_leaves), 3])]
+            consumer_codes = canon if c["parent"] < 0 else clades[c["parent"]]["sub_codes"]
+            assert np.array_equal(sub[rows][:, index], consumer_codes[rows])   # a consumer's pattern carries the clade's codes
+            inner = {n_leaves + d["row"]: d["index"][:U].astype(np.int64) for d in clades if d["parent"] == j}
+            nested += bool(inner)
+            tables[c["root"]] = emulate_program(ops, P, sub, pi, n_states=n, tables=tables, wide=inner)
             assert tables[c["root"]].shape == (U, n)
-            wide[n_leaves + j] = index
+        outer = [c for c in clades if c["parent"] < 0]
+        wide = {n_leaves + c["row"]: c["index"].astype(np.int64) for c in outer}
         table_leaves = main[(main[:, 0] == 1) & (main[:, 3] >= n_leaves)]
-        assert sorted(table_leaves[:, 3]) == list(range(n_leaves, n_leaves + len(clades)))
-        assert sorted(table_leaves[:, 1]) == sorted(c["root"] for c in clades)
+        assert sorted(table_leaves[:, 3]) == sorted(wide) and sorted(table_leaves[:, 1]) == sorted(c["root"] for c in outer)
         n_gemm = lambda ops: int((ops[:, 0] == 0).sum())
         assert n_gemm(main) + sum(n_gemm(c["ops"]) for c in clades) == n_gemm(whole)
         got = emulate_program(main, P, codes, pi, n_states=n, tables=tables, wide=wide)
         np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
-    assert used >= 4
+        seen_nested += nested
+    assert used >= 4 and seen_nested >= 1
