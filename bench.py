@@ -278,9 +278,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         updates_per_eval = world * N_SITES * n_branches * K           # reference units: every site, every branch, every class
-        # With clade tables (subtree site repeats) a step launches the pruning kernel twice -- clade programs over the clades'
-        # distinct sub-patterns, then the main programs -- and executes fewer products than one per (pattern, internal branch,
-        # class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
+        # With clade tables (subtree site repeats) a step launches the pruning kernel several times -- clade programs over the
+        # clades' distinct sub-patterns, one launch per nesting level, then the main programs -- and executes fewer products than
+        # one per (pattern, internal branch, class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
         # stats average); the nominal count of a whole walk stands beside it.
         launches = eng.last_prune_launches()
         kernel_ms_step = float(np.mean(prune_ms))
@@ -313,9 +313,10 @@ def main():
                          "dense_updates_per_launch": dense / launches, "gathered_leaf_updates_per_launch": gather / launches,
                          "executed_dense_updates_per_step": dense, "whole_walk_dense_updates_per_step": nominal_dense,
                          "clade_tables": {"clades": n_clades, "distinct_sub_patterns": sub_patterns,
-                                          "note": "clades of <= 16 leaves are walked once per distinct sub-pattern (launch 1), the main "
-                                                  "programs gather their messages (launch 2); results bit-identical to whole walks "
-                                                  "(tests/test_clade_tables.py); CRAB_NO_CLADE_TABLES=1 restores whole walks"}},
+                                          "note": "clades of <= 64 leaves are walked once per distinct sub-pattern, inner clades first (one "
+                                                  "launch per nesting level), the main programs gather their messages (last launch); "
+                                                  "results bit-identical to whole walks (tests/test_clade_tables.py); "
+                                                  "CRAB_NO_CLADE_TABLES=1 restores whole walks"}},
             "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms_step,
                              "host_eigen": float(np.mean(eigen_ms))},
         }
