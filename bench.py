@@ -274,7 +274,24 @@ def main():
 
     dense, gather = eng.last_work()
     n_clades, sub_patterns = eng.last_clade_tables()
+    launches = eng.last_prune_launches()
     n_pat = eng.n_patterns
+    # Outside the timed region, rank 0 at N = 1: the same evaluations as whole walks (clade tables off) -- the kernel's rate on
+    # one product per (pattern, internal branch, class), the figure of rounds 1 and 2a, for the reader who wants both.
+    whole = None
+    if world == 1 and n_clades > 0 and not args.no_cpu_baseline:
+        eng.set_clade_tables(False)
+        ww = []
+        for i in range(12):
+            eng.site_classes(Qs[i % len(Qs)] * (1.0 + 1e-9 * (i + 1)), case.proportions, case.pi, case.branch_lengths)
+            if i >= 2:
+                ww.append(eng.last_timing()[1])
+        wd = eng.last_work()[0]
+        eng.set_clade_tables(True)
+        w_ms = float(np.mean(ww))
+        w_tf = wd * FLOP_PER_UPDATE / (w_ms * 1e-3) / 1e12
+        whole = {"kernel_ms": w_ms, "dense_updates_per_launch": wd, "achieved": w_tf, "frac": w_tf / FP64_MFMA_PEAK_TFLOPS,
+                 "note": "CRAB_NO_CLADE_TABLES: one launch, one product per (pattern, internal branch, class); 10 evaluations"}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         updates_per_eval = world * N_SITES * n_branches * K           # reference units: every site, every branch, every class
@@ -282,7 +299,6 @@ def main():
         # clades' distinct sub-patterns, one launch per nesting level, then the main programs -- and executes fewer products than
         # one per (pattern, internal branch, class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
         # stats average); the nominal count of a whole walk stands beside it.
-        launches = eng.last_prune_launches()
         kernel_ms_step = float(np.mean(prune_ms))
         kernel_ms = kernel_ms_step / launches
         achieved = dense * FLOP_PER_UPDATE / (kernel_ms_step * 1e-3) / 1e12
@@ -316,7 +332,8 @@ def main():
                                           "note": "clades of <= 64 leaves are walked once per distinct sub-pattern, inner clades first (one "
                                                   "launch per nesting level), the main programs gather their messages (last launch); "
                                                   "results bit-identical to whole walks (tests/test_clade_tables.py); "
-                                                  "CRAB_NO_CLADE_TABLES=1 restores whole walks"}},
+                                                  "CRAB_NO_CLADE_TABLES=1 restores whole walks"},
+                         "whole_walks": whole},
             "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms_step,
                              "host_eigen": float(np.mean(eigen_ms))},
         }

@@ -1972,6 +1972,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         };
         if (!use_clades) bounds(0, n_first, e->dev_bounds_first);
         bounds(n_first, (int)lists.size(), e->dev_bounds_second);
+        for (int pr = 0; pr < n_prog; ++pr) {   // what an item's prologue needs from the ops, so that it need not wait for them
+            ProgHdr &h = hdrs[pr];
+            const DevOp *po = progs.data() + (size_t)pr * prog_stride;
+            h.first_gemm_mat = h.first_gemm_op >= 0 ? po[h.first_gemm_op].mat : -1;
+            h.first_leaf_mat = h.first_leaf_op >= 0 ? po[h.first_leaf_op].mat : -1;
+        }
         e->dev_clades = use_clades;
         e->d_items.ensure(items.size() + 2);
         if (!items.empty())

@@ -98,7 +98,9 @@ struct alignas(16) ProgHdr {
     int32_t save_cls;  // class index inside the save area (the base vector's class with the same rate matrices)
     int32_t no_root;   // 1: a tree part -- the program ends by saving its tile (OP_LOAD with F_SAVE), no site likelihood is written
     int32_t alt_codes; // 1: a clade program -- its leaf rows are read from PruneArgs::codes_alt (the clade's distinct sub-patterns)
-    int32_t pad[3];
+    int32_t first_gemm_mat, first_leaf_mat;   // matrices of ops first_gemm_op / first_leaf_op (-1 none): the item's prologue stages
+                                              // the operand image and requests the columns without reading the ops first
+    int32_t pad;
 };
 // Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
 // of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);

@@ -1147,25 +1147,55 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
     const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
-    for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
+    // An item is found by two dependent scalar loads (item list -> program list) before its header can be read.  Launches of
+    // short programs (clade programs, tree parts, path programs) run a dozen items per workgroup: the next item's program and
+    // tile are looked up before the current item's walk, so that its prologue starts one load away from its data.  (The header
+    // itself is not carried across the walk: the eleven scalar registers it takes push the compiler out of its register budget.)
+    struct ItemDesc {
+        int cls;
+        int tile;
+    };
+    auto locate = [&](long long wi) {
+        ItemDesc d;
         int ci;
-        long long tile;
         if (a.items) {
-            ci = a.items[2 * wi], tile = a.items[2 * wi + 1];
+            ci = a.items[2 * wi], d.tile = a.items[2 * wi + 1];
         } else {
             ci = (int)(wi / n_tiles);
-            tile = wi - (long long)ci * n_tiles;
+            d.tile = (int)(wi - (long long)ci * n_tiles);
         }
-        const int cls = a.cls_list ? a.cls_list[ci] : ci;
-        int n_ops = a.n_ops, first_gemm_op = a.first_gemm_op, first_leaf_row = a.first_leaf_row, first_leaf_op = a.first_leaf_op,
-            second_leaf_row = a.second_leaf_row, third_leaf_row = a.third_leaf_row, save_cls = cls, no_root = 0, alt_codes = 0;
+        d.cls = a.cls_list ? a.cls_list[ci] : ci;
+        return d;
+    };
+    ItemDesc next_item{0, 0};
+    if (chunk_lo + xj < chunk_hi) next_item = locate(chunk_lo + xj);
+    for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
+        struct {
+            int cls;
+            long long tile;
+            ProgHdr h;
+        } item;
+        item.cls = next_item.cls, item.tile = next_item.tile;
         if (a.hdr) {
-            const ProgHdr h = a.hdr[cls];
+            item.h = a.hdr[item.cls];
+        } else {
+            item.h.n_ops = a.n_ops, item.h.first_gemm_op = a.first_gemm_op, item.h.first_leaf_row = a.first_leaf_row;
+            item.h.first_leaf_op = a.first_leaf_op, item.h.second_leaf_row = a.second_leaf_row, item.h.third_leaf_row = a.third_leaf_row;
+            item.h.save_cls = item.cls, item.h.no_root = 0, item.h.alt_codes = 0, item.h.first_gemm_mat = -2, item.h.first_leaf_mat = -2;
+        }
+        if (wi + per_xcd < chunk_hi) next_item = locate(wi + per_xcd);
+        const long long tile = item.tile;
+        const int cls = item.cls;
+        int n_ops, first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row, save_cls, no_root, alt_codes;
+        {
+            const ProgHdr &h = item.h;
             no_root = h.no_root;
             alt_codes = h.alt_codes;
             n_ops = h.n_ops, first_gemm_op = h.first_gemm_op, first_leaf_row = h.first_leaf_row, first_leaf_op = h.first_leaf_op;
             second_leaf_row = h.second_leaf_row, third_leaf_row = h.third_leaf_row, save_cls = h.save_cls;
         }
+        // (-2: no header, the matrices are read from the ops)
+        const int first_gemm_mat = item.h.first_gemm_mat, first_leaf_mat = item.h.first_leaf_mat;
         const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
 
         Walk<NT> w{a};
@@ -1200,14 +1230,15 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 
         __syncthreads();  // every wave is done reading LDS for the previous work item
         __builtin_amdgcn_s_setprio(1);
-        if (first_gemm_op >= 0) dma_matrix(a.P + (size_t)w.ops[first_gemm_op].mat * P_ELEMS, smem, wave, lane);
+        if (first_gemm_op >= 0)
+            dma_matrix(a.P + (size_t)(first_gemm_mat >= 0 ? first_gemm_mat : w.ops[first_gemm_op].mat) * P_ELEMS, smem, wave, lane);
         // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
         w.batch = w.ops[lane];
         if (first_leaf_row >= 0) load_code_offsets<NT>(w, first_leaf_row, w.code_off);
         if constexpr (Plan<NT>::HAS_PRE) {
             if (second_leaf_row >= 0) load_code_offsets<NT>(w, second_leaf_row, w.code_off2);
             if (first_leaf_op >= 0) {
-                issue_columns<NT, Plan<NT>::G>(w, w.ops[first_leaf_op].mat);
+                issue_columns<NT, Plan<NT>::G>(w, first_leaf_mat >= 0 ? first_leaf_mat : w.ops[first_leaf_op].mat);
                 refill_codes1<NT>(w, third_leaf_row);
             }
         }
