@@ -463,7 +463,9 @@ struct crab_engine : TreeProgram {
                                              // (path programs, or root programs); 0: one launch
     int64_t dev_bounds_first[9] = {0}, dev_bounds_second[9] = {0};   // per-XCD chunks of the two launches' work items
     int dev_part_target = 0;            // the tree-part size the uploaded programs were cut for (0: uncut)
-    bool dev_clades = false;            // the uploaded programs are clade programs + main programs
+    bool dev_clades = false;            // the uploaded programs include clade programs + main programs
+    std::vector<int32_t> dev_tabled;    // ... for these classes
+    int dev_first_off = 0;              // entries of the program list that precede the first launch's (the clade launches')
     struct CladeLaunch {                // one launch of clade programs (one level)
         int list_off = 0, n_entries = 0;      // its entries of the program list
         int64_t items_off = 0, n_items = 0;   // its work items
@@ -1759,14 +1761,25 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     // ---- tree parts (a finer work quantum): a single evaluation with few work items per resident workgroup is cut into
     // subtree programs plus a root program (build_tree_parts) ----
-    // ---- clade tables (subtree site repeats; build_clade_tables): single evaluations only -- in a batch the path programs of
-    // partial updates want every internal edge's tiles per pattern ----
+    // ---- clade tables (subtree site repeats; build_clade_tables): every vector that walks the whole tree, except the base
+    // vector of a batch with partial updates (the path programs want every internal edge's tiles per pattern) ----
     bool use_clades = false;
-    if (G == 1 && prune_supports_paths() && e->clade_tables_on && !clade_tables_disabled() && e->n_pat > 0) {
+    std::vector<int32_t> tabled;          // classes (vector b, class k -> b * Kg + k) whose programs gather from clade tables
+    if (prune_supports_paths() && e->clade_tables_on && !clade_tables_disabled() && e->n_pat > 0) {
         if (!e->clades.built) build_clade_tables(e);
-        use_clades = !e->clades.clades.empty();
+        if (!e->clades.clades.empty()) {
+            for (int b = 0; b < G; ++b)
+                if (vec_node[b] < 0 && !(n_path > 0 && b == 0))
+                    for (int k = 0; k < Kg; ++k) tabled.push_back(b * Kg + k);
+            // (every tabled class owns its tables: CRAB_CLADE_TABLE_GB, default 32, bounds what a large batch may take)
+            const double gb = (double)tabled.size() * e->clades.slots_per_class * (P_ELEMS * sizeof(double)) / 1073741824.0;
+            const char *sv = std::getenv("CRAB_CLADE_TABLE_GB");
+            if (gb > (sv && sv[0] ? std::atof(sv) : 32.0)) tabled.clear();
+            use_clades = !tabled.empty();
+        }
     }
     const int n_cl = use_clades ? (int)e->clades.clades.size() : 0;
+    const int n_tab = (int)tabled.size();
     int part_target = 0;
     if (G == 1 && !use_clades && prune_supports_paths() && !tree_parts_disabled() && e->n_gemm_edges >= 8) {
         const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device), n_work = n_tiles * pl.K;
@@ -1794,12 +1807,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     const int n_parts = part_target > 0 ? n_cut : 0;
     // programs 0 .. K-1 write the site likelihoods; part / clade (k, i) is program K + k * n_parts + i
-    const int n_prog = pl.K * (1 + (use_clades ? n_cl : n_parts));
+    const int n_prog = use_clades ? pl.K + n_tab * n_cl : pl.K * (1 + n_parts);
 
     // ---- uploads ----
     const size_t prog_stride = (size_t)dev_ops_padded((int64_t)e->ops.size());
     if (e->dev_ops.empty() || *pidx != e->dev_pidx || vec_node != e->dev_vec_node || part_target != e->dev_part_target ||
-        use_clades != e->dev_clades) {
+        use_clades != e->dev_clades || tabled != e->dev_tabled) {
         // the programs depend on the tree and on these tables only
         DevOp filler{};
         filler.w0 = OP_CONST;
@@ -1818,77 +1831,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         whole.first_gemm_op = e->first_gemm_op, whole.first_leaf_row = e->first_leaf_row, whole.first_leaf_op = e->first_leaf_op;
         whole.second_leaf_row = e->second_leaf_row, whole.third_leaf_row = e->third_leaf_row;
         whole.n_gemm = (int)e->n_gemm_edges, whole.n_leaf = (int)e->n_leaf_edges;
-        int n_first = 0;
+        int n_first = 0, first_off = 0;
         e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
         e->dev_gemm_extra = 0;
         std::vector<int32_t> items;                 // launch 1 of clade tables: (list entry, tile) per work item
-        if (use_clades) {
-            const CladeTables &ct = e->clades;
-            // a program sees the tables it gathers from as the matrices of the clade roots: one patched node -> matrix table per
-            // consumer (a clade, or the main program) and class
-            std::vector<int32_t> pk_c(nn);
-            auto table_mat = [&](int k, int j) { return (int32_t)(M + k * ct.slots_per_class + ct.clades[j].slot_off); };
-            for (int k = 0; k < pl.K; ++k) {
-                const int32_t *pk = pidx->data() + (size_t)k * nn;
-                for (int consumer = -1; consumer < n_cl; ++consumer) {
-                    std::copy(pk, pk + nn, pk_c.begin());
-                    for (int j = 0; j < n_cl; ++j)
-                        if (ct.clades[j].parent == consumer) pk_c[ct.clades[j].root] = table_mat(k, j);
-                    if (consumer < 0) {
-                        resolve_program(ct.main.ops, pk_c.data(), false, progs.data() + (size_t)k * prog_stride);
-                        header(k, ct.main.info, k, 0);
-                    } else {
-                        const PathProgram &pp = ct.clades[consumer].prog;
-                        const int prog = pl.K + k * n_cl + consumer;
-                        DevOp *po = progs.data() + (size_t)prog * prog_stride;
-                        resolve_program(pp.ops, pk_c.data(), false, po);
-                        po[pp.ops.size() - 1].mat = table_mat(k, consumer);   // the table store
-                        header(prog, pp.info, k, 1);
-                        hdrs[prog].alt_codes = 1;
-                    }
-                }
-            }
-            // one launch per level: class-major (one class's matrices stay together), clades with most products first
-            e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
-            for (int l = 0; l < ct.n_levels; ++l) {
-                crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
-                cl.list_off = (int)lists.size();
-                cl.items_off = (int64_t)items.size() / 2;
-                std::vector<int> order;
-                for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
-                std::stable_sort(order.begin(), order.end(),
-                                 [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
-                std::vector<double> item_w;
-                for (int k = 0; k < pl.K; ++k)
-                    for (int j : order) {
-                        const int entry = (int)lists.size() - cl.list_off;
-                        lists.push_back(pl.K + k * n_cl + j);
-                        const ProgInfo &in = ct.clades[j].prog.info;
-                        for (int64_t t = 0; t < ct.clades[j].tiles; ++t) {
-                            items.push_back(entry);
-                            items.push_back((int32_t)t);
-                            item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
-                        }
-                        e->dev_gemm_extra += (int64_t)in.n_gemm * ct.clades[j].tiles * prune_tile_width();
-                    }
-                cl.n_entries = (int)lists.size() - cl.list_off;
-                cl.n_items = (int64_t)item_w.size();
-                // one chunk of the launch's items per XCD, of equal work
-                double total = 0.0, acc = 0.0;
-                for (double w : item_w) total += w;
-                int x = 1;
-                cl.bounds[0] = 0;
-                for (size_t i = 0; i < item_w.size() && x < 8; ++i) {
-                    acc += item_w[i];
-                    while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
-                }
-                while (x <= 8) cl.bounds[x++] = (int64_t)item_w.size();
-            }
-            n_first = (int)lists.size();
-            for (int k = 0; k < pl.K; ++k) lists.push_back(k);
-            e->dev_gemm_per_pat = (int64_t)pl.K * ct.main.info.n_gemm;
-            e->dev_leaf_per_pat = (int64_t)pl.K * ct.main.info.n_leaf;
-        } else if (n_parts > 0) {
+        if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
                 const int32_t *pk = pidx->data() + (size_t)k * nn;
@@ -1912,7 +1859,78 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             e->dev_gemm_per_pat = (int64_t)pl.K * e->n_gemm_edges;
             e->dev_leaf_per_pat = (int64_t)pl.K * e->n_leaf_edges;
         } else {
+            std::vector<char> is_tabled(pl.K, 0);
+            e->dev_clade_launches.clear();
+            if (use_clades) {
+                const CladeTables &ct = e->clades;
+                // a program sees the tables it gathers from as the matrices of the clade roots: one patched node -> matrix table per
+                // consumer (a clade, or the main program) and tabled class
+                std::vector<int32_t> pk_c(nn);
+                auto table_mat = [&](int t, int j) { return (int32_t)(M + t * ct.slots_per_class + ct.clades[j].slot_off); };
+                for (int t = 0; t < n_tab; ++t) {
+                    const int c = tabled[t];
+                    is_tabled[c] = 1;
+                    const int32_t *pk = pidx->data() + (size_t)c * nn;
+                    for (int consumer = -1; consumer < n_cl; ++consumer) {
+                        std::copy(pk, pk + nn, pk_c.begin());
+                        for (int j = 0; j < n_cl; ++j)
+                            if (ct.clades[j].parent == consumer) pk_c[ct.clades[j].root] = table_mat(t, j);
+                        if (consumer < 0) {
+                            resolve_program(ct.main.ops, pk_c.data(), false, progs.data() + (size_t)c * prog_stride);
+                            header(c, ct.main.info, c % Kg, 0);
+                        } else {
+                            const PathProgram &pp = ct.clades[consumer].prog;
+                            const int prog = pl.K + t * n_cl + consumer;
+                            DevOp *po = progs.data() + (size_t)prog * prog_stride;
+                            resolve_program(pp.ops, pk_c.data(), false, po);
+                            po[pp.ops.size() - 1].mat = table_mat(t, consumer);   // the table store
+                            header(prog, pp.info, c % Kg, 1);
+                            hdrs[prog].alt_codes = 1;
+                        }
+                    }
+                    e->dev_gemm_per_pat += ct.main.info.n_gemm;
+                    e->dev_leaf_per_pat += ct.main.info.n_leaf;
+                }
+                // one launch per level: class-major (one class's matrices stay together), clades with most products first
+                e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
+                for (int l = 0; l < ct.n_levels; ++l) {
+                    crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+                    cl.list_off = (int)lists.size();
+                    cl.items_off = (int64_t)items.size() / 2;
+                    std::vector<int> order;
+                    for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
+                    std::stable_sort(order.begin(), order.end(),
+                                     [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
+                    std::vector<double> item_w;
+                    for (int t = 0; t < n_tab; ++t)
+                        for (int j : order) {
+                            const int entry = (int)lists.size() - cl.list_off;
+                            lists.push_back(pl.K + t * n_cl + j);
+                            const ProgInfo &in = ct.clades[j].prog.info;
+                            for (int64_t tl = 0; tl < ct.clades[j].tiles; ++tl) {
+                                items.push_back(entry);
+                                items.push_back((int32_t)tl);
+                                item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
+                            }
+                            e->dev_gemm_extra += (int64_t)in.n_gemm * ct.clades[j].tiles * prune_tile_width();
+                        }
+                    cl.n_entries = (int)lists.size() - cl.list_off;
+                    cl.n_items = (int64_t)item_w.size();
+                    // one chunk of the launch's items per XCD, of equal work
+                    double total = 0.0, acc = 0.0;
+                    for (double w : item_w) total += w;
+                    int x = 1;
+                    cl.bounds[0] = 0;
+                    for (size_t i = 0; i < item_w.size() && x < 8; ++i) {
+                        acc += item_w[i];
+                        while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
+                    }
+                    while (x <= 8) cl.bounds[x++] = (int64_t)item_w.size();
+                }
+            }
+            first_off = (int)lists.size();
             for (int b = 0; b < G; ++b) {
+                if (is_tabled[(size_t)b * Kg]) continue;
                 const PathProgram *pp = nullptr;
                 if (vec_node[b] >= 0) {
                     auto it = e->path_programs.find(vec_node[b]);
@@ -1934,7 +1952,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             for (int b = 0; b < G; ++b)
                 if (vec_node[b] < 0)
                     for (int k = 0; k < Kg; ++k) lists.push_back(b * Kg + k);
-            n_first = (int)lists.size();
+            n_first = (int)lists.size() - first_off;
             std::vector<int> order;
             for (int b = 0; b < G; ++b)
                 if (vec_node[b] >= 0) order.push_back(b);
@@ -1970,8 +1988,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             out[8] = (int64_t)(hi - lo) * n_tiles;
             for (int y = 1; y <= 8; ++y) out[y] = std::max(out[y], out[y - 1]);
         };
-        if (!use_clades) bounds(0, n_first, e->dev_bounds_first);
-        bounds(n_first, (int)lists.size(), e->dev_bounds_second);
+        bounds(first_off, first_off + n_first, e->dev_bounds_first);
+        bounds(first_off + n_first, (int)lists.size(), e->dev_bounds_second);
         for (int pr = 0; pr < n_prog; ++pr) {   // what an item's prologue needs from the ops, so that it need not wait for them
             ProgHdr &h = hdrs[pr];
             const DevOp *po = progs.data() + (size_t)pr * prog_stride;
@@ -1979,6 +1997,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             h.first_leaf_mat = h.first_leaf_op >= 0 ? po[h.first_leaf_op].mat : -1;
         }
         e->dev_clades = use_clades;
+        e->dev_tabled = tabled;
+        e->dev_first_off = first_off;
         e->d_items.ensure(items.size() + 2);
         if (!items.empty())
             HIP_CHECK(hipMemcpyAsync(e->d_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
@@ -1986,7 +2006,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         e->dev_vec_node = vec_node;
         e->dev_part_target = part_target;
         e->dev_n_first = n_first;
-        e->dev_n_second = (int)lists.size() - n_first;
+        e->dev_n_second = (int)lists.size() - first_off - n_first;
         e->d_ops.ensure(progs.size());
         e->d_hdr.ensure(hdrs.size());
         e->d_cls.ensure(lists.size() + 1);
@@ -2012,16 +2032,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_small.ensure(n_small);
     double *d_teff = e->d_small.p, *d_pi = d_teff + M, *d_props = d_pi + NS;
     int32_t *d_eig_id = reinterpret_cast<int32_t *>(d_props + pl.K);
-    e->d_P.ensure(((size_t)M + (use_clades ? (size_t)pl.K * e->clades.slots_per_class : 0)) * P_ELEMS);
-    int64_t n_items_first = n_tiles * n_first;
-    if (use_clades) {
-        n_items_first = 0;
-        for (const auto &cl : e->dev_clade_launches) n_items_first = std::max(n_items_first, cl.n_items);
-    }
-    const int grid = prune_grid_size(n_items_first, e->device);
+    e->d_P.ensure(((size_t)M + (use_clades ? (size_t)n_tab * e->clades.slots_per_class : 0)) * P_ELEMS);
+    int64_t n_items_max = n_tiles * n_first;
+    if (use_clades)
+        for (const auto &cl : e->dev_clade_launches) n_items_max = std::max(n_items_max, cl.n_items);
+    const int grid = prune_grid_size(n_tiles * n_first, e->device);
     const int grid_second = two_launches ? prune_grid_size(n_tiles * n_second, e->device) : 0;
-    e->d_stack.ensure(prune_stack_doubles(std::max(grid, grid_second), e->max_depth));
-    e->d_stack_e.ensure(prune_stack_ints(std::max(grid, grid_second), e->max_depth));
+    const int grid_max = std::max({grid, grid_second, prune_grid_size(n_items_max, e->device)});
+    e->d_stack.ensure(prune_stack_doubles(grid_max, e->max_depth));
+    e->d_stack_e.ensure(prune_stack_ints(grid_max, e->max_depth));
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_patlnl.ensure((size_t)G * e->n_pat_pad);
@@ -2048,9 +2067,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.n_ops_pad = (int32_t)dev_ops_padded((int64_t)e->ops.size());
     pa.P = e->d_P.p;
     pa.K = n_first;
-    pa.hdr = two_launches ? e->d_hdr.p : nullptr;
-    pa.cls_list = two_launches ? e->d_cls.p : nullptr;
-    pa.save = two_launches ? (char *)e->d_save.p : nullptr;
+    const bool lists_used = two_launches || use_clades;
+    pa.hdr = lists_used ? e->d_hdr.p : nullptr;
+    pa.cls_list = lists_used ? e->d_cls.p + e->dev_first_off : nullptr;
+    pa.save = (n_path > 0 || n_parts > 0) ? (char *)e->d_save.p : nullptr;
     pa.save_K = Kg;
     std::copy(e->dev_bounds_first, e->dev_bounds_first + 9, pa.xcd_bounds);
     pa.codes = e->d_codes.p;
@@ -2069,32 +2089,29 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.third_leaf_row = e->third_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     if (use_clades) {     // one launch per level: the clade programs, over each clade's distinct sub-patterns
-        pa.save = nullptr;
-        pa.n_code_rows = e->aln_rows;
+        PruneArgs pc = pa;
+        pc.save = nullptr;
+        pc.n_code_rows = e->aln_rows;
         for (size_t l = 0; l < e->dev_clade_launches.size(); ++l) {
             const crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
-            pa.K = cl.n_entries;
-            pa.cls_list = e->d_cls.p + cl.list_off;
-            pa.items = e->d_items.p + 2 * cl.items_off;
-            pa.n_items = cl.n_items;
-            pa.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
-            pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
-            std::copy(cl.bounds, cl.bounds + 9, pa.xcd_bounds);
-            launch_prune(pa, prune_grid_size(cl.n_items, e->device), e->stream);
+            pc.K = cl.n_entries;
+            pc.cls_list = e->d_cls.p + cl.list_off;
+            pc.items = e->d_items.p + 2 * cl.items_off;
+            pc.n_items = cl.n_items;
+            pc.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
+            pc.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
+            std::copy(cl.bounds, cl.bounds + 9, pc.xcd_bounds);
+            launch_prune(pc, prune_grid_size(cl.n_items, e->device), e->stream);
         }
-    } else {
-        launch_prune(pa, grid, e->stream);
+        // the main programs (among the first launch's) read the outermost clades' tables through the last block of wide rows
+        pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
+        pa.n_code_rows = e->aln_rows;
     }
-    if (two_launches) {   // path programs / root programs / main programs read what the first launch left: same stream, after it
+    launch_prune(pa, grid, e->stream);
+    if (two_launches) {   // path programs / root programs read what the first launch saved: same stream, after it
         pa.K = n_second;
-        pa.cls_list = e->d_cls.p + n_first;
+        pa.cls_list = e->d_cls.p + e->dev_first_off + n_first;
         std::copy(e->dev_bounds_second, e->dev_bounds_second + 9, pa.xcd_bounds);
-        if (use_clades) {
-            pa.items = nullptr;
-            pa.n_items = 0;
-            pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
-            pa.n_code_rows = e->aln_rows;
-        }
         launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
@@ -2223,10 +2240,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->last_M = M;
     e->last_dense = e->dev_gemm_per_pat * e->n_pat + e->dev_gemm_extra;     // products and gathers actually executed
     e->last_gather = e->dev_leaf_per_pat * e->n_pat;
-    e->last_n_path = (n_parts > 0 || use_clades) ? 0 : n_second / std::max(1, Kg);
+    e->last_n_path = n_parts > 0 ? 0 : n_second / std::max(1, Kg);
     e->last_n_parts = n_parts;
     e->last_n_clades = n_cl;
-    e->last_n_launches = use_clades ? (int)e->dev_clade_launches.size() + 1 : (two_launches ? 2 : 1);
+    e->last_n_launches = (use_clades ? (int)e->dev_clade_launches.size() : 0) + 1 + (two_launches ? 1 : 0);
 
     if (pl.post_weights) {
         const double *src = e->h_out.p + G;

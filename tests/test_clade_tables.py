@@ -102,6 +102,35 @@ def test_batches_and_shards(gpu_engine_cls):
         assert eng.last_clade_tables()[0] > 0
         assert np.array_equal(batch, singles)
         one = singles[0]
+        # a whole gradient stencil: branch rows take path programs on the base vector's tiles (whole walk), the rows that move a
+        # model parameter walk the whole tree -- through clade tables of their own
+        B2 = nn + 3
+        bl2 = np.repeat(case.branch_lengths[None], B2, 0)
+        bl2[np.arange(1, nn), np.arange(nn - 1)] *= 1.0 + 1e-6
+        ka2, om2, pr2 = np.full(B2, case.kappa), np.repeat(case.class_omegas[None], B2, 0), np.repeat(np.asarray(case.proportions)[None], B2, 0)
+        ka2[nn] *= 1.0 + 1e-6
+        om2[nn + 1, 2] *= 1.0 + 1e-6
+        om2[nn + 2, 10] *= 1.0 + 1e-6
+        grad = eng.codon_site_classes(ka2, om2, pr2, case.pi, bl2)
+        assert eng.last_partial_updates() == nn - 1 and eng.last_clade_tables()[0] > 0
+        dense_mixed = eng.last_work()[0]
+        eng.set_clade_tables(False)
+        grad_off = eng.codon_site_classes(ka2, om2, pr2, case.pi, bl2)
+        assert eng.last_work()[0] > dense_mixed and np.array_equal(grad, grad_off)
+        eng.set_clade_tables(True)
+        want = np.array([eng.codon_site_classes(ka2[b], om2[b], pr2[b], case.pi, bl2[b]) for b in range(B2)])
+        assert np.array_equal(grad, want)
+        # unrelated vectors (no single-branch structure): every one of them through tables
+        rng = np.random.default_rng(4)
+        B3 = 5
+        ka3 = case.kappa * rng.uniform(0.8, 1.2, B3)
+        bl3 = case.branch_lengths[None] * rng.uniform(0.7, 1.3, (B3, nn))
+        got3 = eng.codon_site_classes(ka3, om2[:B3], pr2[:B3], case.pi, bl3)
+        assert eng.last_partial_updates() == 0 and eng.last_clade_tables()[0] > 0
+        want3 = np.array([eng.codon_site_classes(ka3[b], om2[b], pr2[b], case.pi, bl3[b]) for b in range(B3)])
+        eng.set_clade_tables(False)
+        off3 = eng.codon_site_classes(ka3, om2[:B3], pr2[:B3], case.pi, bl3)
+        assert np.array_equal(got3, want3) and np.array_equal(got3, off3)
     eng = gpu_engine_cls([0, 0, 0])
     try:
         eng.set_tree(case.parent, case.leaf_node_ids)

@@ -55,7 +55,12 @@ def test_site_class_models_on_three_shards(gpu_engine_cls):
         p1 = one.codon_class_posteriors(ka[:3], om[:3], prb[:3], w, pi, bl)
         p3 = many.codon_class_posteriors(ka[:3], om[:3], prb[:3], w, pi, bl)
         assert np.array_equal(p1, p3)
-        # introspection adds up
+        # introspection adds up (whole walks: with clade tables every shard counts the products of its own clades' sub-patterns)
+        assert one.last_clade_tables()[0] > 0 and many.last_clade_tables()[0] > one.last_clade_tables()[0]
+        for eng in (one, many):
+            eng.set_clade_tables(False)
+        assert np.array_equal(one.codon_class_posteriors(ka[:3], om[:3], prb[:3], w, pi, bl), p1)
+        assert np.array_equal(many.codon_class_posteriors(ka[:3], om[:3], prb[:3], w, pi, bl), p1)
         d1, g1 = one.last_work()
         d3, g3 = many.last_work()
         assert (d1, g1) == (d3, g3)
