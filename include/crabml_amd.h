@@ -84,7 +84,8 @@ int crab_create_multi(const int *devices, int n_devices, crab_engine **out);
  * stay bit-identical.  The environment variable CRAB_DEVICE_EIGEN=1 sets the default of new engines. */
 int crab_set_eigensolver(crab_engine *e, int on_device);
 /* Clade tables (subtree site repeats; on by default, CRAB_NO_CLADE_TABLES=1 switches them off for every engine).  The reference
- * computes every column at every node (likelihood.rs:176-195).  A single evaluation (one parameter vector) instead walks each
+ * computes every column at every node (likelihood.rs:176-195).  An evaluation (every vector of a batched call that walks the
+ * whole tree, except the base vector of a batch with partial updates) instead walks each
  * chosen clade -- a subtree of at most 64 leaves whose leaves show few distinct sub-patterns; clades nest -- once per distinct
  * sub-pattern and lets whatever contains it gather the clade's message per (sub-)pattern; bit-identical to whole walks, a multiple fewer
  * products on alignments of related sequences.  crab_last_clade_tables: clades used by the last evaluation (0: whole walks)
