@@ -1022,6 +1022,9 @@ void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows,
     for (int v = 0; v < nn; ++v)
         if (e->reachable[v] && !e->in_leaf_set[v] && e->op_fin[v] >= 0) internal.push_back(v);
     std::sort(internal.begin(), internal.end(), [&](int a, int b) { return e->op_fin[a] < e->op_fin[b]; });
+    // the plan keeps a 4-byte sub-pattern id per (candidate node, pattern) on the host while it is made: alignments for which that
+    // would pass CRAB_CLADE_PLAN_GB (default 8) are walked whole
+    if ((double)internal.size() * (double)n_pat * 4.0 > env_num("CRAB_CLADE_PLAN_GB", 8.0) * 1073741824.0) return;
     // ---- distinct sub-patterns of every candidate node, bottom-up: a node's sub-pattern is the tuple of its children's ----
     std::vector<int> n_rows(nn, 0);
     std::vector<char> cand(nn, 0);
