@@ -399,6 +399,7 @@ struct TreeProgram {
     std::vector<char> in_leaf_set, reachable;
     std::vector<TreeOp> ops;
     int max_depth = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
+    int second_leaf_op = -1, fourth_leaf_row = -1;
     int64_t n_gemm_edges = 0, n_leaf_edges = 0;
     // for path programs (partial updates): the ops that multiply a term into each node, in program order, and the op
     // that crosses the branch above each internal node
@@ -412,6 +413,7 @@ struct TreeProgram {
 // What the kernel needs to know about one program besides its ops.
 struct ProgInfo {
     int n_ops = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
+    int second_leaf_op = -1, fourth_leaf_row = -1;   // a program that opens with two leaf edges of one node: see finalise_program
     int n_gemm = 0, n_leaf = 0;
 };
 // A path program: what changes when only the branch above `node` moves (see build_path_program).
@@ -615,6 +617,15 @@ void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info)
     const int reg_slots = prune_reg_stack_slots();
     int li = 0;                                  // leaf_ops[li] = next leaf edge not yet consumed
     int req = info.first_leaf_op == 0 ? 1 : 0;     // how many of the upcoming leaf edges have been requested (0..2)
+    // A program that opens with two leaf edges of one node (a cherry; most clade programs): the item's prologue requests both
+    // at once, the first into G and the second into the landing tile, which nothing uses before the first product.  (With
+    // one request the second gather started when the first had landed: a whole round trip with nothing to hide it.)
+    if (req == 1 && n_leaf >= 2 && leaf_ops[1] == 1 && (ops[1].flags & F_MUL_PROD)) {
+        ops[1].flags |= F_IN_LANDING;
+        info.second_leaf_op = 1;
+        info.fourth_leaf_row = leaf_row(3);
+        req = 2;
+    }
     for (int i = 0; i < (int)ops.size(); ++i) {
         TreeOp &op = ops[i];
         const bool next_is_leaf = i + 1 < (int)ops.size() && ops[i + 1].kind == OP_LEAF;
@@ -842,6 +853,8 @@ void build_tree(TreeProgram *e, int n_nodes, const int32_t *node_ids, const int3
     e->first_leaf_op = info.first_leaf_op;
     e->second_leaf_row = info.second_leaf_row;
     e->third_leaf_row = info.third_leaf_row;
+    e->second_leaf_op = info.second_leaf_op;
+    e->fourth_leaf_row = info.fourth_leaf_row;
 }
 
 // The program that recomputes the root's conditional likelihood when only the branch above `node` has changed, on the
@@ -1826,6 +1839,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             ProgHdr &h = hdrs[prog];
             h.n_ops = in.n_ops, h.first_gemm_op = in.first_gemm_op, h.first_leaf_row = in.first_leaf_row;
             h.first_leaf_op = in.first_leaf_op, h.second_leaf_row = in.second_leaf_row, h.third_leaf_row = in.third_leaf_row;
+            h.second_leaf_mat = in.second_leaf_op, h.fourth_leaf_row = in.fourth_leaf_row;   // (op index for now: resolved below)
             h.save_cls = save_cls;
             h.no_root = no_root;
         };
@@ -1833,6 +1847,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         whole.n_ops = (int)e->ops.size();
         whole.first_gemm_op = e->first_gemm_op, whole.first_leaf_row = e->first_leaf_row, whole.first_leaf_op = e->first_leaf_op;
         whole.second_leaf_row = e->second_leaf_row, whole.third_leaf_row = e->third_leaf_row;
+        whole.second_leaf_op = e->second_leaf_op, whole.fourth_leaf_row = e->fourth_leaf_row;
         whole.n_gemm = (int)e->n_gemm_edges, whole.n_leaf = (int)e->n_leaf_edges;
         int n_first = 0, first_off = 0;
         e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
@@ -1998,6 +2013,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             const DevOp *po = progs.data() + (size_t)pr * prog_stride;
             h.first_gemm_mat = h.first_gemm_op >= 0 ? po[h.first_gemm_op].mat : -1;
             h.first_leaf_mat = h.first_leaf_op >= 0 ? po[h.first_leaf_op].mat : -1;
+            h.second_leaf_mat = h.second_leaf_mat >= 0 ? po[h.second_leaf_mat].mat : -1;
         }
         e->dev_clades = use_clades;
         e->dev_tabled = tabled;
@@ -2090,6 +2106,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.first_leaf_op = e->first_leaf_op;
     pa.second_leaf_row = e->second_leaf_row;
     pa.third_leaf_row = e->third_leaf_row;
+    pa.second_leaf_op = e->second_leaf_op;
+    pa.fourth_leaf_row = e->fourth_leaf_row;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     if (use_clades) {     // one launch per level: the clade programs, over each clade's distinct sub-patterns
         PruneArgs pc = pa;

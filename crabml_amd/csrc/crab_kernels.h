@@ -57,7 +57,8 @@ enum : int32_t {
     F_PRE_LATE = 64,  // any op: at its end, request the columns of leaf edge pre_node (the next op is that leaf edge)
     F_PRE_DYING = 128,  // GEMM: also request the columns of leaf edge pre_node_b into the registers of the product's B
                         // operand as they die, k-tile by k-tile; they are then in the landing tile of the ops that follow
-    F_IN_LANDING = 256, // LEAF (with F_MUL_PROD): the columns were requested by the preceding product's F_PRE_DYING
+    F_IN_LANDING = 256, // LEAF (with F_MUL_PROD): the columns were requested by the preceding product's F_PRE_DYING, or (op 1 of
+                        // a program with ProgHdr::second_leaf_mat / PruneArgs::second_leaf_op set) by the item's prologue
     // partial updates (a finite-difference stencil row that moves one branch re-walks only the path from that branch to
     // the root, on tiles the base vector's walk left in HBM): see "save area" below
     F_POP_SAVED = 512,  // GEMM with F_POP_MUL (path programs): the saved product is save slot `slot`, not stack slot `slot`
@@ -100,7 +101,8 @@ struct alignas(16) ProgHdr {
     int32_t alt_codes; // 1: a clade program -- its leaf rows are read from PruneArgs::codes_alt (the clade's distinct sub-patterns)
     int32_t first_gemm_mat, first_leaf_mat;   // matrices of ops first_gemm_op / first_leaf_op (-1 none): the item's prologue stages
                                               // the operand image and requests the columns without reading the ops first
-    int32_t pad;
+    int32_t second_leaf_mat;   // >= 0: the program opens with two leaf edges of one node and this is the second one's matrix -- the
+    int32_t fourth_leaf_row;   // prologue requests its columns into the landing tile; the code queue then continues at this row
 };
 // Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
 // of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);
@@ -153,6 +155,8 @@ struct PruneArgs {
     int32_t first_leaf_op;    // index of that op if it is op 0 (its columns are requested before the walk starts), else -1
     int32_t second_leaf_row;  // alignment rows of the second and third leaf edges (-1 if none)
     int32_t third_leaf_row;
+    int32_t second_leaf_op;   // 1: ops 0 and 1 are leaf edges of one node, both requested by the prologue (op 1 into the landing
+    int32_t fourth_leaf_row;  //    tile); the code queue then continues at this row.  -1: only op 0 is
     // Clade tables (subtree site repeats).  A clade whose leaves show U << n_pat distinct sub-patterns is walked once per
     // sub-pattern by a clade program (launch 1, codes_alt, work items from `items`); the message of its root's branch lands in a
     // table laid out like a gather image of U columns, and the main program reads it like a leaf edge: alignment rows >=

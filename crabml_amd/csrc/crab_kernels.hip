@@ -460,6 +460,9 @@ struct Plan {
 template <int D, int A, int B, bool FIRST>
 __device__ __forceinline__ void r_mfma()
 {
+#ifdef CRAB_ABLATE_MFMA
+    return;
+#endif
     if constexpr (FIRST)
         asm volatile("v_mfma_f64_4x4x4_4b_f64 v[%0:%1], v[%2:%3], v[%4:%5], 0" ::"n"(D), "n"(D + 1), "n"(A), "n"(A + 1), "n"(B), "n"(B + 1));
     else
@@ -562,6 +565,13 @@ __device__ __forceinline__ void t_gather_seq(const void *sbase, unsigned voff, s
 {
     (r_gload128<D + 4 * Q, 64 * Q>(sbase, voff), ...);
 }
+#ifdef CRAB_ABLATE_COALESCE
+template <int D, int... Q>
+__device__ __forceinline__ void t_gather_block_seq(const void *sbase, unsigned voff, std::integer_sequence<int, Q...>)
+{
+    (r_gload128<D + 4 * Q, 1024 * (Q & 3)>(sbase, voff + (Q >> 2) * 4096), ...);
+}
+#endif
 // stack slot <-> tile.  A saved tile is laid out like a block of 16 gather-image columns (pattern c at c * 512 bytes,
 // the lane's 16-byte piece q at 64 q + 16 g; voff = (lane & 15) * 512 + (lane >> 4) * 16): eight 16-byte accesses per
 // lane.  (In this layout a pop can also ride inside the product that precedes it, through Ride::img_b; measured
@@ -703,19 +713,31 @@ struct Ride {
         } else if constexpr (GI % 2 == 1 && G >= 0) {
             if (img) {
                 constexpr int q = (GI - 17) / 2;
+#ifdef CRAB_ABLATE_COALESCE
+                r_gload128<(G >= 0 ? G : 0) + 4 * q, 1024 * (q & 3)>(img, voff + (q >> 2) * 4096);
+#else
                 r_gload128<(G >= 0 ? G : 0) + 4 * q, 64 * q>(img, voff);
+#endif
             }
         } else if constexpr (GI % 4 == 0 && GI >= 4 && G >= 0) {
             if (img_b) {
                 constexpr int q = GI / 4 - 1;
+#ifdef CRAB_ABLATE_COALESCE
+                r_gload128<XB + 4 * q, 1024 * (q & 3)>(img_b, voff_b + (q >> 2) * 4096);
+#else
                 r_gload128<XB + 4 * q, 64 * q>(img_b, voff_b);
+#endif
             }
         }
     }
     __device__ __forceinline__ void after() const
     {
         if constexpr (G >= 0)
+#ifdef CRAB_ABLATE_COALESCE
+            if (img_b) r_gload128<XB + 28, 1024 * 3>(img_b, voff_b + 4096);
+#else
             if (img_b) r_gload128<XB + 28, 64 * 7>(img_b, voff_b);
+#endif
     }
 };
 template <int NT, int X, int Y, int GI, typename R>
@@ -796,7 +818,14 @@ __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, un
     if (w.a.n_code_rows > 0 && row >= w.a.n_code_rows) {   // a clade's table: the column of this pattern's sub-pattern (wave-uniform branch)
         const uint32_t *r = w.idx + (size_t)(row - w.a.n_code_rows) * w.a.n_pat_pad;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) code[nt] = r[nt * 16];
+        for (int nt = 0; nt < NT; ++nt) {
+#ifdef CRAB_ABLATE_CODES
+            code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
+            (void)r;
+#else
+            code[nt] = r[nt * 16];
+#endif
+        }
     } else {
         const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
 #pragma unroll
@@ -810,7 +839,13 @@ __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, un
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
+    for (int nt = 0; nt < NT; ++nt) {
+#ifdef CRAB_ABLATE_COALESCE
+        off[nt] = ((unsigned)__builtin_amdgcn_readfirstlane((int)code[nt]) & ~15u) * 512u + (unsigned)w.lane * 16u;
+#else
+        off[nt] = code[nt] * 512u + (unsigned)(w.lane >> 4) * 16u;
+#endif
+    }
 }
 // The code queue holds the offsets of the next two leaf edges whose columns have not been requested yet
 // (code_off, code_off2).  One request took the head: shift, and fetch the codes of alignment row `row` behind it.
@@ -836,8 +871,16 @@ __device__ __forceinline__ void issue_columns(Walk<NT> &w, int mat)
     // (readfirstlane: the "s" operand of the loads must be provably wave-uniform)
     const char *img = w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8);
     using S8 = std::make_integer_sequence<int, 8>;
+#ifdef CRAB_ABLATE_GATHER
+    (void)img;
+#else
+#ifdef CRAB_ABLATE_COALESCE   // the same 8 KiB per tile as one contiguous block: what the scattered 64-byte pieces cost
+    t_gather_block_seq<D>(img, w.code_off[0], S8{});
+#else
     t_gather_seq<D>(img, w.code_off[0], S8{});
     if constexpr (NT == 2) t_gather_seq<D + 32>(img, w.code_off[1], S8{});
+#endif
+#endif
 }
 // Kernels without a prefetch tile: columns now, then the codes of the next leaf edge (alignment row `row_next`).
 template <int NT, int D>
@@ -987,6 +1030,12 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             ride.voff_b = pre_g ? w.code_off2[0] : w.code_off[0];
             // Outside a product a wave is on its latency-bound critical path (gathers, multiplies, barriers) while
             // the other wave of the SIMD feeds the MFMA pipe: give that path the issue priority (measured +2 %).
+#ifdef CRAB_ABLATE_GATHER
+            ride.img = ride.img_b = nullptr;
+#endif
+#ifdef CRAB_ABLATE_DMA
+            ride.dma_src = nullptr;
+#endif
             __builtin_amdgcn_s_setprio(0);
             gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768, ride);
             __builtin_amdgcn_s_setprio(1);
@@ -1064,7 +1113,9 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
                     int ex = eX[0];
                     ex = ex < -1022 ? -1022 : ex > 1023 ? 1023 : ex;
                     t_scale_seq<X>(__hiloint2double((1023 + ex) << 20, 0), std::make_integer_sequence<int, 16>{});
+#ifndef CRAB_ABLATE_TABLE_STORE   // (CRAB_ABLATE_*: timing experiments with wrong results, scripts/gpu_ablate.sh)
                     t_store<NT, X>((char *)w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8) + w.table_off, w.stack_voff);
+#endif
                 } else if (flags & F_SAVE) {
                     save_tile<NT, X>(w, sv, eX);
                 } else if (flags & F_MUL_PROD) {
@@ -1182,6 +1233,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             item.h.n_ops = a.n_ops, item.h.first_gemm_op = a.first_gemm_op, item.h.first_leaf_row = a.first_leaf_row;
             item.h.first_leaf_op = a.first_leaf_op, item.h.second_leaf_row = a.second_leaf_row, item.h.third_leaf_row = a.third_leaf_row;
             item.h.save_cls = item.cls, item.h.no_root = 0, item.h.alt_codes = 0, item.h.first_gemm_mat = -2, item.h.first_leaf_mat = -2;
+            item.h.second_leaf_mat = a.second_leaf_op >= 0 ? -2 : -1, item.h.fourth_leaf_row = a.fourth_leaf_row;
         }
         if (wi + per_xcd < chunk_hi) next_item = locate(wi + per_xcd);
         const long long tile = item.tile;
@@ -1196,6 +1248,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         }
         // (-2: no header, the matrices are read from the ops)
         const int first_gemm_mat = item.h.first_gemm_mat, first_leaf_mat = item.h.first_leaf_mat;
+        const int second_leaf_mat = item.h.second_leaf_mat, fourth_leaf_row = item.h.fourth_leaf_row;
         const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
 
         Walk<NT> w{a};
@@ -1225,12 +1278,22 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             e0[nt] = e1[nt] = 0;
+#ifdef CRAB_ABLATE_COALESCE
+            w.code_off[nt] = w.code_off2[nt] = (unsigned)lane * 16u;
+#else
             w.code_off[nt] = w.code_off2[nt] = (unsigned)a.n_states * 512u + (unsigned)g * 16u;
+#endif
         }
 
+#ifndef CRAB_ABLATE_ITEM_SYNC
         __syncthreads();  // every wave is done reading LDS for the previous work item
+#endif
         __builtin_amdgcn_s_setprio(1);
+#ifndef CRAB_ABLATE_DMA
         if (first_gemm_op >= 0)
+#else
+        if (false)
+#endif
             dma_matrix(a.P + (size_t)(first_gemm_mat >= 0 ? first_gemm_mat : w.ops[first_gemm_op].mat) * P_ELEMS, smem, wave, lane);
         // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
         w.batch = w.ops[lane];
@@ -1240,6 +1303,10 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             if (first_leaf_op >= 0) {
                 issue_columns<NT, Plan<NT>::G>(w, first_leaf_mat >= 0 ? first_leaf_mat : w.ops[first_leaf_op].mat);
                 refill_codes1<NT>(w, third_leaf_row);
+                if (second_leaf_mat != -1) {   // op 1 is the same node's second leaf edge: into the landing tile, in the same round trip
+                    issue_columns<NT, X1>(w, second_leaf_mat >= 0 ? second_leaf_mat : w.ops[1].mat);
+                    refill_codes1<NT>(w, fourth_leaf_row);
+                }
             }
         }
 
