@@ -429,6 +429,10 @@ void launch_eigen(const double *S, const int32_t *slot, const double *sqrt_pi, d
 // busiest frame depths; on trees of Sethi-Ullman depth <= 2 no conditional likelihood ever leaves the register
 // file.  The other slots (and every slot with NT = 2) go to the global-memory stack.
 constexpr int N_XCD = 8;  // the launch grid is a multiple of this
+#ifndef CRAB_PRIO_CORE   // issue priorities of a wave inside a product and outside one (experiments: -DCRAB_PRIO_CORE=.. -DCRAB_PRIO_OTHER=..)
+#define CRAB_PRIO_CORE 0
+#define CRAB_PRIO_OTHER 1
+#endif
 // -DCRAB_NO_PATH_OPS compiles the save / load ops of partial updates and tree parts out of the kernel (same-box A/B of
 // what their presence costs a plain walk; such a build must run with CRAB_NO_PATH_UPDATES=1 CRAB_NO_TREE_PARTS=1)
 #ifdef CRAB_NO_PATH_OPS
@@ -1036,9 +1040,9 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
 #ifdef CRAB_ABLATE_DMA
             ride.dma_src = nullptr;
 #endif
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(CRAB_PRIO_CORE);
             gemm_tile<NT, X, Y>(w.lds_a + w.buf * 32768, ride);
-            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(CRAB_PRIO_OTHER);
             if (pre_g && pre_b)
                 refill_codes2<NT>(w, pre_row2, pre_row3);
             else if (pre_g || pre_b)
@@ -1288,7 +1292,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #ifndef CRAB_ABLATE_ITEM_SYNC
         __syncthreads();  // every wave is done reading LDS for the previous work item
 #endif
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(CRAB_PRIO_OTHER);
 #ifndef CRAB_ABLATE_DMA
         if (first_gemm_op >= 0)
 #else
