@@ -1610,7 +1610,17 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     double *h_eig = e->h_eig.p;
     std::vector<char> ok(todo.size(), 1);
     std::vector<double> Qbuilt(by_params ? todo.size() * (size_t)n * n : 0);
+    static const bool debug_times = std::getenv("CRAB_DEBUG_EIGEN_TIMES") != nullptr;   // per-task start / end, to stderr
+    std::vector<double> dbg_t0(debug_times ? todo.size() : 0), dbg_t1(dbg_t0.size());
+    const auto dbg_origin = std::chrono::steady_clock::now();
+    auto dbg_now = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_origin).count(); };
     auto decompose_one = [&](int j) {
+        struct Stamp {
+            double *t0, *t1;
+            const decltype(dbg_now) &now;
+            Stamp(double *a, double *b, const decltype(dbg_now) &n) : t0(a), t1(b), now(n) { if (t0) *t0 = now(); }
+            ~Stamp() { if (t1) *t1 = now(); }
+        } stamp(debug_times ? &dbg_t0[j] : nullptr, debug_times ? &dbg_t1[j] : nullptr, dbg_now);
         const int i = uniq_src[todo[j]];
         const double *Qi = Q + (size_t)i * n * n;
         if (by_params) {
@@ -1667,6 +1677,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         });
     } else {
         parallel_for((int)todo.size(), decompose_one);
+    }
+    if (debug_times && !device_eigen && !todo.empty()) {
+        std::string line = "[crab eigen] " + std::to_string(todo.size()) + " decompositions, all done at " + std::to_string((int)dbg_now()) + " us:";
+        for (size_t j = 0; j < todo.size(); ++j) line += " " + std::to_string((int)dbg_t0[j]) + "-" + std::to_string((int)dbg_t1[j]);
+        fprintf(stderr, "%s\n", line.c_str());
     }
     for (size_t j = 0; j < todo.size(); ++j)
         if (!ok[j]) fail(CRAB_ERR_EIGEN, "Eigendecomposition failed for rate matrix " + std::to_string(uniq_src[todo[j]]));
