@@ -1484,6 +1484,7 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
 // kernel 3: mixture / log / sum
 // =============================================================================================
 constexpr int MIX_THREADS = 256;
+constexpr int MIX_CACHED = 16;   // classes whose log terms mix_kernel keeps in registers between its two passes
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 // ln(fs * 2^e), with the reference's clamp max(f, 1e-300) applied in log space when asked
@@ -1519,6 +1520,11 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
     a.props += grp * a.K;
     a.pat_lnl += grp * a.n_pat_pad;
     a.partials += grp * gridDim.x;
+    __shared__ double lp[MIX_CACHED];   // ln p_k, once per workgroup
+    if (a.mode != MIX_LINEAR && a.K <= MIX_CACHED) {
+        if ((int)threadIdx.x < a.K) lp[threadIdx.x] = log(a.props[threadIdx.x]);
+        __syncthreads();
+    }
     double contrib = 0.0;
     if (p < a.n_pat) {
         double lnf;
@@ -1540,16 +1546,33 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
             // x_k = ln max(f_k, 1e-300) + ln p_k ; max + ln sum exp(x - max)  (likelihood.rs:349-370)
             const bool clamp = a.mode == MIX_LOGSUMEXP_CLAMP;
             double mx = -__builtin_inf();
-            for (int k = 0; k < a.K; ++k) {
-                const size_t o = (size_t)k * a.n_pat_pad + p;
-                const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
-                mx = x > mx ? x : mx;
-            }
             double s = 0.0;
-            for (int k = 0; k < a.K; ++k) {
-                const size_t o = (size_t)k * a.n_pat_pad + p;
-                const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
-                s += exp(x - mx);
+            if (a.K <= MIX_CACHED) {
+                // the usual case (M8: 11 classes): every x_k is computed once and kept in a register for the second pass
+                // (the same expression as below, so the same bits: this kernel's transcendental functions were 18 of a step's
+                // 1 100 us at configs[1], on the 39 CUs its grid reaches)
+                double xs[MIX_CACHED];
+#pragma unroll
+                for (int k = 0; k < MIX_CACHED; ++k)
+                    if (k < a.K) {
+                        const size_t o = (size_t)k * a.n_pat_pad + p;
+                        xs[k] = ln_site(a.f[o], a.e[o], clamp) + lp[k];
+                        mx = xs[k] > mx ? xs[k] : mx;
+                    }
+#pragma unroll
+                for (int k = 0; k < MIX_CACHED; ++k)
+                    if (k < a.K) s += exp(xs[k] - mx);
+            } else {
+                for (int k = 0; k < a.K; ++k) {
+                    const size_t o = (size_t)k * a.n_pat_pad + p;
+                    const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
+                    mx = x > mx ? x : mx;
+                }
+                for (int k = 0; k < a.K; ++k) {
+                    const size_t o = (size_t)k * a.n_pat_pad + p;
+                    const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
+                    s += exp(x - mx);
+                }
             }
             lnf = mx + log(s);
         }
