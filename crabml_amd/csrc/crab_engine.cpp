@@ -2060,7 +2060,15 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     for (int i = 0; i < NS; ++i) hs[M + i] = i < n ? pi[i] : 0.0;
     for (int k = 0; k < pl.K; ++k) hs[M + NS + k] = pl.props.empty() ? 1.0 : pl.props[k];
     int32_t *h_ids = reinterpret_cast<int32_t *>(hs + M + NS + pl.K);
-    for (int m = 0; m < M; ++m) h_ids[m] = mat_slot[m];
+    {   // which image of each matrix has a reader: leaf edges are gathered from, all other edges multiplied with
+        std::vector<uint8_t> used(M, 0);
+        const size_t n_cls = pidx->size() / (size_t)nn;
+        for (size_t c = 0; c < n_cls; ++c)
+            for (int v = 0; v < nn; ++v)
+                if (v != e->root && e->reachable[v]) used[(*pidx)[c * nn + v]] |= e->in_leaf_set[v] ? 1 : 2;
+        for (int m = 0; m < M; ++m)   // (a matrix nobody reads keeps both images: crab_export_transition_matrices shows it)
+            h_ids[m] = mat_slot[m] | (used[m] == 1 ? BUILD_P_NO_OPERAND : used[m] == 2 ? BUILD_P_NO_GATHER : 0);
+    }
     if (M & 1) h_ids[M] = 0;
 
     e->d_small.ensure(n_small);
@@ -2901,8 +2909,9 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out)
         for (int v = 0; v < nn; ++v) {
             const double *Pm = img.data() + (size_t)e->last_pidx[(size_t)k * nn + v] * P_ELEMS;
             double *out = P_out + (size_t)v * n * n;
+            const bool gathered = v != e->root && e->reachable[v] && e->in_leaf_set[v];   // a leaf edge has its gather image only
             for (int i = 0; i < n; ++i)
-                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] = Pm[p_operand_index(i, j)];
+                for (int j = 0; j < n; ++j) out[(size_t)i * n + j] = Pm[gathered ? p_gather_index(i, j) : p_operand_index(i, j)];
         }
     });
 }

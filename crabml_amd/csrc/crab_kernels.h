@@ -115,7 +115,9 @@ inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 +
 
 // ---- kernel 1: batched P(t) = U diag(exp(lam t)) U^-1  (replaces matrix.rs:88-112) -----------
 // For m in [0, M): eigensystem eig + eig_id[m]*EIG_STRIDE, time t_eff[m]; writes P + m*P_ELEMS in
-// fragment order with row sums in column n_states.
+// fragment order with row sums in column n_states.  eig_id[m] may carry BUILD_P_NO_OPERAND / BUILD_P_NO_GATHER: that image of
+// matrix m is then left unwritten (nothing reads a leaf edge's operand image or an internal edge's gather image).
+constexpr int32_t BUILD_P_NO_GATHER = 1 << 29, BUILD_P_NO_OPERAND = 1 << 30;
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
                     bool clamp_negative, hipStream_t stream);
 

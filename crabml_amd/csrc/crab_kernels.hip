@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256, 2) void build_p_kernel(const double *__restric
     double a[16][4];
     int cur = -1;
     for (int m = m0; m < m1; ++m) {
-        const int id = __builtin_amdgcn_readfirstlane(eig_id[m]);
+        // (bits 29 and 30 of the entry: this matrix's gather / operand image has no reader -- a leaf edge is only ever
+        // gathered from, an internal edge only ever multiplied with -- and is not written)
+        const int raw_id = __builtin_amdgcn_readfirstlane(eig_id[m]);
+        const int id = raw_id & (BUILD_P_NO_GATHER - 1);
+        const bool store_operand = !(raw_id & BUILD_P_NO_OPERAND), store_gather = !(raw_id & BUILD_P_NO_GATHER);
         const double *E = eig + (size_t)id * EIG_STRIDE;
         const double *UT = E + EIG_UT, *Uinv = E + EIG_UINV, *lam = E + EIG_LAM;
         if (id != cur) {
@@ -114,12 +118,14 @@ __global__ __launch_bounds__(256, 2) void build_p_kernel(const double *__restric
                 if (jt == ns_jt && r == ns_r && g == ns_g) v0 = rs;
                 if (jt == ns_jt && r + 1 == ns_r && g == ns_g) v1 = rs;
                 const int j0 = 16 * jt + 4 * r + g, j1 = j0 + 4;
-                *(v2d *)(out + p_operand_index(i, j0)) = (v2d){v0, v1};
+                if (store_operand) *(v2d *)(out + p_operand_index(i, j0)) = (v2d){v0, v1};
                 // what the partner lane (c ^ 4) needs from this lane: its column is j1 if this lane is the low half, j0 otherwise
-                const double give = hi_half ? v0 : v1;
-                const double got = __shfl_xor(give, 4);
-                const v2d pair = hi_half ? (v2d){got, v1} : (v2d){v0, got};
-                *(v2d *)(out + p_gather_index(i & ~4, hi_half ? j1 : j0)) = pair;
+                if (store_gather) {
+                    const double give = hi_half ? v0 : v1;
+                    const double got = __shfl_xor(give, 4);
+                    const v2d pair = hi_half ? (v2d){got, v1} : (v2d){v0, got};
+                    *(v2d *)(out + p_gather_index(i & ~4, hi_half ? j1 : j0)) = pair;
+                }
             }
     }
 }
@@ -129,7 +135,10 @@ void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_ef
 {
     if (M <= 0) return;
     // one round of workgroups (two fit a CU at this kernel's register count), each with a run of the matrix list
-    const int per_wg = (M + 511) / 512, grid = (M + per_wg - 1) / per_wg;
+    int per_wg = (M + 511) / 512;
+    static const int per_wg_env = std::getenv("CRAB_BUILD_P_PER_WG") ? std::atoi(std::getenv("CRAB_BUILD_P_PER_WG")) : 0;   // experiments
+    if (per_wg_env > 0) per_wg = per_wg_env;
+    const int grid = (M + per_wg - 1) / per_wg;
     hipLaunchKernelGGL(build_p_kernel, dim3(grid), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0, M, per_wg);
 }
 
