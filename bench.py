@@ -171,8 +171,8 @@ def target_workload(device, with_cpu=True, evals=8, cpu_sample=1000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target", action="store_true", help="skip the north_star target workload block (M8, 500 taxa x 50 000 codons)")
     ap.add_argument("--fd-batch", type=int, default=0,
