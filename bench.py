@@ -333,6 +333,12 @@ def main():
                                                   "launch per nesting level), the main programs gather their messages (last launch); "
                                                   "results bit-identical to whole walks (tests/test_clade_tables.py); "
                                                   "CRAB_NO_CLADE_TABLES=1 restores whole walks"},
+                         "reference_algorithm_equivalent": {
+                             "achieved": nominal_dense * FLOP_PER_UPDATE / (kernel_ms_step * 1e-3) / 1e12,
+                             "frac": nominal_dense * FLOP_PER_UPDATE / (kernel_ms_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             "note": "the products of the reference's algorithm (one per pattern, internal branch and class: SURVEY 8(d)'s "
+                                     "unit) over the same kernel time; above 1 only because most of them are not executed -- the kernel's own "
+                                     "rate is `frac` above"},
                          "whole_walks": whole},
             "breakdown_ms": {"device_section": float(np.mean(device_ms)), "prune_kernel": kernel_ms_step,
                              "host_eigen": float(np.mean(eigen_ms))},
