@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
                     ej_sqrt_rsqrt(big * big + b2 * b2, root, inv);
                     c = big * inv;
                     sn = (d >= 0.0 ? b2 : -b2) * inv;
-                    ++made_here;
+                    // a rotation is "quiet" if both the entry and the angle are below 2^-32 (relative): see the end of the sweep
+                    made_here += (apq * apq > 5.421010862427522e-20 * fabs(app * aqq) || fabs(sn) > 2.3283064365386963e-10) ? 0x10001 : 1;
                     clear = true;
                 } else if (apq != 0.0) {
                     clear = true;                               // negligible: drop it (both copies) so that it cannot creep back
@@ -307,12 +308,16 @@ __global__ __launch_bounds__(256) void eigen_kernel(const double *__restrict__ S
             }
             EJ_MARK(4)
         }
-        if (made_here) atomicAdd(n_rot, made_here);
+        if (made_here) atomicAdd(n_rot, made_here);             // rotations in the low half, the loud ones among them in the high half
         __syncthreads();
         const int made = *n_rot;
         __syncthreads();
         if (t == 0) *n_rot = 0;                                 // (the next count is 126 barriers away)
-        if (made == 0) break;
+        // Done when a sweep rotates nothing -- or only quietly: with every entry at most eps = 2^-32 of its diagonal pair when
+        // its turn came and every sine at most 2^-32, what the sweep's other rotations put back into a cleared entry is at
+        // most n eps^2 = 2^-58, below the 2^-53 at which a pair is left alone; the sweep that would find that out (a ninth
+        // of the kernel's time) is not run.
+        if ((made >> 16) == 0) break;
         if (sweep == max_sweeps - 1 && t == 0) atomicOr(status, 1);   // still rotating after the last sweep: the engine fails the call
     }
 #ifdef EJ_PROF
