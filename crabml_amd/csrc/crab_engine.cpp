@@ -1595,6 +1595,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     }
     const int n_uniq = (int)uniq_src.size();
+    const double t_grouped = now_ms();
     std::vector<int32_t> pool_slot(n_uniq, -1);
     std::vector<int> todo;
     auto look_up = [&](int u) {
@@ -1611,6 +1612,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         for (int u = 0; u < n_uniq; ++u) look_up(u);
     for (int u = 0; u < n_uniq; ++u)
         if (pool_slot[u] < 0) todo.push_back(u);
+    if (std::getenv("CRAB_DEBUG_EIGEN_TIMES") && n_uniq >= 64)
+        fprintf(stderr, "[crab eigen] %d matrices: hashing and grouping %.3f ms, look-ups %.3f ms, %zu to decompose\n", n_uniq, t_grouped - t0,
+                now_ms() - t_grouped, todo.size());
     e->eig_hits += n_uniq - (int)todo.size();
     e->eig_misses += (int)todo.size();
     const bool device_eigen = e->device_eigen && !todo.empty();
