@@ -28,20 +28,58 @@ def pattern_slices(n_patterns: int, world_size: int, align: int = 128):
     return out
 
 
-def ordered_sum(partial: float, group=None, device=None) -> float:
-    """Sum of one double per rank, accumulated in rank order (deterministic, identical on every rank)."""
+_GATHER_BUFFERS = {}   # (group id, device, n) -> buffers of all_gather_doubles, made once: the step loop allocates nothing
+
+
+def all_gather_doubles(vec, group=None, device=None) -> "np.ndarray":
+    """ONE collective: every rank contributes ``n`` doubles and gets the [world_size, n] table, rows in rank order.
+    Over RCCL the send and receive buffers live on the device and their host mirrors are pinned, all four made once per
+    (group, device, n): a call is one host-to-device copy of n doubles, one ``all_gather_into_tensor`` and one copy
+    back, on the current stream, with a single synchronisation at the end (no per-rank tensors, no ``cat``).  Small
+    payloads only (partial sums, per-grid-point terms); big tables go through ``gather_site_table``."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return float(partial)
+    vec = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1)
     ws = dist.get_world_size(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    mine = torch.tensor([partial], dtype=torch.float64, device=device)
-    parts = [torch.empty_like(mine) for _ in range(ws)]
-    dist.all_gather(parts, mine, group=group)
+    device = torch.device(device)
+    n = vec.size
+    key = (id(group) if group is not None else 0, str(device), n)
+    buf = _GATHER_BUFFERS.get(key)
+    if buf is None:
+        on_gpu = device.type == "cuda"
+        host_send = torch.empty(n, dtype=torch.float64, pin_memory=on_gpu)
+        host_recv = torch.empty(ws * n, dtype=torch.float64, pin_memory=on_gpu)
+        dev_send = torch.empty(n, dtype=torch.float64, device=device) if on_gpu else host_send
+        dev_recv = torch.empty(ws * n, dtype=torch.float64, device=device) if on_gpu else host_recv
+        if len(_GATHER_BUFFERS) >= 64:    # payload sizes are few in practice (1, B, G); do not grow without bound
+            _GATHER_BUFFERS.clear()
+        buf = _GATHER_BUFFERS[key] = (host_send, dev_send, dev_recv, host_recv)
+    host_send, dev_send, dev_recv, host_recv = buf
+    host_send.numpy()[:] = vec
+    if dev_send is not host_send:
+        with torch.cuda.device(device):
+            dev_send.copy_(host_send, non_blocking=True)
+            dist.all_gather_into_tensor(dev_recv, dev_send, group=group)
+            host_recv.copy_(dev_recv, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+    else:
+        dist.all_gather_into_tensor(dev_recv, dev_send, group=group)
+    return host_recv.numpy().reshape(ws, n).copy()
+
+
+def _single_rank(group) -> bool:
+    import torch.distributed as dist
+    return not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1
+
+
+def ordered_sum(partial: float, group=None, device=None) -> float:
+    """Sum of one double per rank, accumulated in rank order (deterministic, identical on every rank)."""
+    if _single_rank(group):
+        return float(partial)
     total = 0.0
-    for p in torch.cat(parts).cpu().tolist():
+    for p in all_gather_doubles([partial], group, device)[:, 0].tolist():
         total += p
     return total
 
@@ -49,21 +87,14 @@ def ordered_sum(partial: float, group=None, device=None) -> float:
 def ordered_sum_vector(partials, group=None, device=None):
     """``ordered_sum`` for a vector: the B partial log-likelihoods of a batched evaluation (a point and its
     finite-difference neighbours) in ONE all-gather, summed in rank order on every rank."""
-    import torch
-    import torch.distributed as dist
     partials = np.asarray(partials, dtype=np.float64)
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _single_rank(group):
         return partials
-    ws = dist.get_world_size(group)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    mine = torch.from_numpy(np.ascontiguousarray(partials)).to(device)
-    parts = [torch.empty_like(mine) for _ in range(ws)]
-    dist.all_gather(parts, mine, group=group)
-    total = np.zeros_like(partials)
-    for part in parts:
-        total = total + part.cpu().numpy()
-    return total
+    table = all_gather_doubles(partials, group, device)
+    total = np.zeros(partials.size)
+    for row in table:
+        total = total + row
+    return total.reshape(partials.shape)
 
 
 class ShardedLikelihood:
@@ -178,19 +209,12 @@ def sharded_beb_grid(engine, Q, pi, branch_lengths, cols, props, group=None, dev
     the slices' per-grid-point log-likelihoods are summed across ranks (one all-gather of G doubles, added in rank
     order so that every rank holds the same bits) before each rank integrates the posteriors of its own sites.
     Returns (posteriors [n_sites, n_mix] with NaN rows for other ranks' sites, ln f(X))."""
-    import torch
-    import torch.distributed as dist
     _, part, _ = engine.beb_grid(Q, pi, branch_lengths, cols, props, partial=True)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        ws = dist.get_world_size(group)
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        mine = torch.from_numpy(part).to(device)
-        parts = [torch.empty_like(mine) for _ in range(ws)]
-        dist.all_gather(parts, mine, group=group)
-        total = np.zeros_like(part)
-        for p_ in parts:
-            total = total + p_.cpu().numpy()
+    if not _single_rank(group):
+        total = np.zeros(part.size)
+        for row in all_gather_doubles(part, group, device):
+            total = total + row
+        total = total.reshape(part.shape)
     else:
         total = part
     post, _, ln_fx = engine.beb_grid(Q, pi, branch_lengths, cols, props, lnfx=total)

@@ -315,3 +315,56 @@ def test_two_rank_gloo_fit_over_pattern_slices_equals_the_single_rank_fit():
     # a different summation order moves f by ~1e-13, the 1e-8-step gradient by ~1e-5, and the iterates with it
     np.testing.assert_allclose(res[0][0], want, rtol=1e-3)
     assert abs(res[0][0][-1] - want[-1]) < 1e-6 * abs(want[-1])
+
+
+def _gather_worker(rank, world, port, out, backend):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from crabml_amd import dist as cd
+        rows = []
+        for n in (1, 5, 1, 203):        # sizes repeat: the second use of a size runs on the buffers of the first
+            mine = np.arange(n, dtype=np.float64) * 0.1 + 1000.0 * (rank + 1) + n
+            rows.append(cd.all_gather_doubles(mine))
+        # one rank: the public helpers short-cut, so the collective is exercised through all_gather_doubles above
+        s = cd.ordered_sum(0.1 * (rank + 1))
+        v = cd.ordered_sum_vector(np.array([[1.0, 2.0], [3.0, 4.0]]) * (rank + 1))
+        out[rank] = ([r.tolist() for r in rows], s, v.tolist(), len(cd._GATHER_BUFFERS))
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_gather(out, world):
+    for rank in range(world):
+        rows, s, v, n_buf = out[rank]
+        for n, table in zip((1, 5, 1, 203), rows):
+            want = [(np.arange(n) * 0.1 + 1000.0 * (r + 1) + n).tolist() for r in range(world)]
+            assert table == want
+        acc = 0.0
+        for r in range(world):
+            acc += 0.1 * (r + 1)
+        assert s == acc
+        assert v == (np.array([[1.0, 2.0], [3.0, 4.0]]) * sum(range(1, world + 1))).tolist()
+        assert n_buf <= 4                   # one set of buffers per payload size (1, 5, 203, and the 2 x 2 vector if world > 1)
+
+
+def test_two_rank_gloo_all_gather_of_doubles_reuses_its_buffers():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gather_worker, args=(world, _free_port(), out, "gloo"), nprocs=world, join=True)
+        _check_gather(dict(out), world)
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_of_doubles_on_one_rank():
+    """The RCCL leg of all_gather_doubles (pinned mirrors, device buffers, all_gather_into_tensor) on the box's one
+    GPU: a one-rank communicator is the most this box can hold (two ranks on one card are refused by RCCL)."""
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gather_worker, args=(1, _free_port(), out, "nccl"), nprocs=1, join=True)
+        _check_gather(dict(out), 1)
