@@ -184,10 +184,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    # The contract is ONE JSON line on stdout.  gloo and RCCL write banners to file descriptor 1 when a communicator comes up
+    # ("[Gloo] Rank 0 is connected ...", "RCCL version : ..."): everything but the JSON line goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from crabml_amd import synth
-    from crabml_amd.dist import ordered_sum
+    from crabml_amd.dist import all_gather_doubles, ordered_sum
     from crabml_amd.engine import Engine
 
     if not torch.cuda.is_available():
@@ -197,9 +203,12 @@ def main():
     backend = os.environ.get("CRAB_BENCH_BACKEND", "nccl")
     if os.environ.get("CRAB_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    # CRAB_BENCH_FORCE_DIST=1 (rehearsal too): a ONE-rank run under torch.distributed.run goes through the whole N > 1 set-up
+    # (gloo control group, RCCL data group, probe, agreement) and exchanges its partial sum over RCCL every step.
+    force_dist = os.environ.get("CRAB_BENCH_FORCE_DIST") == "1" and world == 1
     torch.cuda.set_device(local_rank)
     data_group = None
-    if world > 1:
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             # The ranks must agree on the backend: a rank that fell back to gloo on its own while the others sit in an
@@ -247,10 +256,12 @@ def main():
 
     def step():
         partial = eng.site_classes(next(it), case.proportions, case.pi, case.branch_lengths)
+        if force_dist:            # ordered_sum short-cuts on one rank: call the collective it is built on
+            return float(all_gather_doubles([partial], group=data_group)[:, 0].sum())
         return ordered_sum(partial, group=data_group)
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -321,7 +332,8 @@ def main():
                                    "random bushy tree, tree length %.2f subst/codon, 1%% gap codons" % case.tree_length,
                        "taxa": N_TAXA, "codons_per_gpu": N_SITES, "patterns_per_gpu": n_pat, "classes": K,
                        "branches": n_branches, "sharding": f"patterns over {world} GPU(s)",
-                       "collective": "none" if world == 1 else ("rccl" if backend == "nccl" else backend), "lnL": lnL},
+                       "collective": "none" if world == 1 and not force_dist else ("rccl" if backend == "nccl" else backend),
+                       "lnL": lnL},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "prune_kernel_nt1", "kernel_ms": kernel_ms, "launches_per_step": launches,
@@ -365,8 +377,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_target:
             out["target_workload"] = target_workload(local_rank, with_cpu=not args.no_cpu_baseline)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
