@@ -1523,6 +1523,65 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return s;  // valid on thread 0
 }
 
+// One pattern's term of the sum: the class mixture, its log (stored per pattern) and the pattern weight.  `a` already
+// points at the group's slices; lp = ln p_k in LDS when K <= MIX_CACHED.
+__device__ __forceinline__ double mix_pattern(const MixArgs &a, long long p, const double *lp)
+{
+    if (p >= a.n_pat) return 0.0;
+    double lnf;
+    if (a.mode == MIX_LINEAR) {
+        // ln sum_k freq_k f_k  (branch_site_likelihood.rs:162-168), evaluated around the largest exponent
+        int emax = -2147483647 - 1;
+        for (int k = 0; k < a.K; ++k) {
+            const int ek = a.e[(size_t)k * a.n_pat_pad + p];
+            emax = ek > emax ? ek : emax;
+        }
+        double s = 0.0;
+        for (int k = 0; k < a.K; ++k) {
+            const size_t o = (size_t)k * a.n_pat_pad + p;
+            const int d = a.e[o] - emax;
+            s += a.props[k] * (d < -2000 ? 0.0 : ldexp(a.f[o], d));
+        }
+        lnf = log(s) + (double)emax * LN2;
+    } else {
+        // x_k = ln max(f_k, 1e-300) + ln p_k ; max + ln sum exp(x - max)  (likelihood.rs:349-370)
+        const bool clamp = a.mode == MIX_LOGSUMEXP_CLAMP;
+        double mx = -__builtin_inf();
+        double s = 0.0;
+        if (a.K <= MIX_CACHED) {
+            // the usual case (M8: 11 classes): every x_k is computed once and kept in a register for the second pass
+            // (the same expression as below, so the same bits: this kernel's transcendental functions were 18 of a step's
+            // 1 100 us at configs[1], on the 39 CUs its grid reaches)
+            double xs[MIX_CACHED];
+#pragma unroll
+            for (int k = 0; k < MIX_CACHED; ++k)
+                if (k < a.K) {
+                    const size_t o = (size_t)k * a.n_pat_pad + p;
+                    xs[k] = ln_site(a.f[o], a.e[o], clamp) + lp[k];
+                    mx = xs[k] > mx ? xs[k] : mx;
+                }
+#pragma unroll
+            for (int k = 0; k < MIX_CACHED; ++k)
+                if (k < a.K) s += exp(xs[k] - mx);
+        } else {
+            for (int k = 0; k < a.K; ++k) {
+                const size_t o = (size_t)k * a.n_pat_pad + p;
+                const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
+                mx = x > mx ? x : mx;
+            }
+            for (int k = 0; k < a.K; ++k) {
+                const size_t o = (size_t)k * a.n_pat_pad + p;
+                const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
+                s += exp(x - mx);
+            }
+        }
+        lnf = mx + log(s);
+    }
+    a.pat_lnl[p] = lnf;
+    const double wgt = a.weights[p];
+    return wgt != 0.0 ? wgt * lnf : 0.0;
+}
+
 // blockIdx.y = group (one parameter vector of a batched evaluation): classes [y*K, (y+1)*K) with their own proportions
 __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
 {
@@ -1539,63 +1598,40 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_kernel(MixArgs a)
         if ((int)threadIdx.x < a.K) lp[threadIdx.x] = log(a.props[threadIdx.x]);
         __syncthreads();
     }
-    double contrib = 0.0;
-    if (p < a.n_pat) {
-        double lnf;
-        if (a.mode == MIX_LINEAR) {
-            // ln sum_k freq_k f_k  (branch_site_likelihood.rs:162-168), evaluated around the largest exponent
-            int emax = -2147483647 - 1;
-            for (int k = 0; k < a.K; ++k) {
-                const int ek = a.e[(size_t)k * a.n_pat_pad + p];
-                emax = ek > emax ? ek : emax;
-            }
-            double s = 0.0;
-            for (int k = 0; k < a.K; ++k) {
-                const size_t o = (size_t)k * a.n_pat_pad + p;
-                const int d = a.e[o] - emax;
-                s += a.props[k] * (d < -2000 ? 0.0 : ldexp(a.f[o], d));
-            }
-            lnf = log(s) + (double)emax * LN2;
-        } else {
-            // x_k = ln max(f_k, 1e-300) + ln p_k ; max + ln sum exp(x - max)  (likelihood.rs:349-370)
-            const bool clamp = a.mode == MIX_LOGSUMEXP_CLAMP;
-            double mx = -__builtin_inf();
-            double s = 0.0;
-            if (a.K <= MIX_CACHED) {
-                // the usual case (M8: 11 classes): every x_k is computed once and kept in a register for the second pass
-                // (the same expression as below, so the same bits: this kernel's transcendental functions were 18 of a step's
-                // 1 100 us at configs[1], on the 39 CUs its grid reaches)
-                double xs[MIX_CACHED];
-#pragma unroll
-                for (int k = 0; k < MIX_CACHED; ++k)
-                    if (k < a.K) {
-                        const size_t o = (size_t)k * a.n_pat_pad + p;
-                        xs[k] = ln_site(a.f[o], a.e[o], clamp) + lp[k];
-                        mx = xs[k] > mx ? xs[k] : mx;
-                    }
-#pragma unroll
-                for (int k = 0; k < MIX_CACHED; ++k)
-                    if (k < a.K) s += exp(xs[k] - mx);
-            } else {
-                for (int k = 0; k < a.K; ++k) {
-                    const size_t o = (size_t)k * a.n_pat_pad + p;
-                    const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
-                    mx = x > mx ? x : mx;
-                }
-                for (int k = 0; k < a.K; ++k) {
-                    const size_t o = (size_t)k * a.n_pat_pad + p;
-                    const double x = ln_site(a.f[o], a.e[o], clamp) + log(a.props[k]);
-                    s += exp(x - mx);
-                }
-            }
-            lnf = mx + log(s);
-        }
-        a.pat_lnl[p] = lnf;
-        const double wgt = a.weights[p];
-        contrib = wgt != 0.0 ? wgt * lnf : 0.0;
-    }
-    const double s = block_sum(contrib, red);
+    const double s = block_sum(mix_pattern(a, p, lp), red);
     if (threadIdx.x == 0) a.partials[blockIdx.x] = s;
+}
+
+// Few patterns (configs[0]: 7 taxa x 130 codons is one block of 256): mix_kernel and final_sum_kernel as ONE launch.  One
+// workgroup per group walks the nb <= MIX_FUSED_BLOCKS blocks of 256 patterns that mix_kernel's grid would have held, takes
+// each block's sum with the same reduction, keeps the partial sums in LDS, and adds them as final_sum_kernel does (thread i
+// holds partial i, then the same tree): the same bits, one launch less per evaluation.  The limit is ONE block: with two
+// (a 30 x 400 gene) the workgroup's second pass over the classes' logs and exponentials costs more than the launch it saves
+// (device section 0.147 against 0.140 ms, profiles/r2_fused_mix_timing.txt); the loop stays for the record of that trial.
+constexpr int MIX_FUSED_BLOCKS = 1;
+__global__ __launch_bounds__(MIX_THREADS) void mix_final_kernel(MixArgs a, int nb)
+{
+    __shared__ double red[MIX_THREADS / 64];
+    __shared__ double part[MIX_FUSED_BLOCKS];
+    const size_t grp = blockIdx.x;
+    a.f += grp * a.K * a.n_pat_pad;
+    a.e += grp * a.K * a.n_pat_pad;
+    a.props += grp * a.K;
+    a.pat_lnl += grp * a.n_pat_pad;
+    __shared__ double lp[MIX_CACHED];
+    if (a.mode != MIX_LINEAR && a.K <= MIX_CACHED) {
+        if ((int)threadIdx.x < a.K) lp[threadIdx.x] = log(a.props[threadIdx.x]);
+        __syncthreads();
+    }
+    for (int b = 0; b < nb; ++b) {
+        const double s = block_sum(mix_pattern(a, (long long)b * MIX_THREADS + threadIdx.x, lp), red);
+        if (threadIdx.x == 0) part[b] = s;
+        __syncthreads();   // red is reused by the next block's sum; part[b] is read below
+    }
+    double v = 0.0;
+    if ((int)threadIdx.x < nb) v += part[threadIdx.x];
+    const double s = block_sum(v, red);
+    if (threadIdx.x == 0) a.lnL[grp] = s;
 }
 
 // fixed-order final sum: one workgroup, strided partial sums then a tree
@@ -1617,6 +1653,11 @@ void launch_mix(const MixArgs &a, hipStream_t stream)
     const int nb = mix_blocks(a.n_pat);
     if (nb <= 0) return;
     const int ng = a.n_groups > 0 ? a.n_groups : 1;
+    static const bool no_fused = std::getenv("CRAB_NO_FUSED_MIX") != nullptr;   // A/B and the bit-identity test
+    if (nb <= MIX_FUSED_BLOCKS && !no_fused) {
+        hipLaunchKernelGGL(mix_final_kernel, dim3(ng), dim3(MIX_THREADS), 0, stream, a, nb);
+        return;
+    }
     hipLaunchKernelGGL(mix_kernel, dim3(nb, ng), dim3(MIX_THREADS), 0, stream, a);
     hipLaunchKernelGGL(final_sum_kernel, dim3(ng), dim3(MIX_THREADS), 0, stream, a.partials, nb, a.lnL);
 }
