@@ -1,6 +1,8 @@
-"""Kernel 3 with few patterns: mix_kernel + final_sum_kernel run as ONE launch (mix_final_kernel) when the patterns fit
+"""The end of an evaluation, two switches.  Kernel 3 with few patterns: mix_kernel + final_sum_kernel run as ONE launch (mix_final_kernel) when the patterns fit
 one block of 256.  The fused launch must give the bits of the two launches: the same evaluations are repeated in a
-child process with CRAB_NO_FUSED_MIX=1 (the switch is read once per process) and compared as hexadecimal floats."""
+child process with CRAB_NO_FUSED_MIX=1 (the switch is read once per process) and compared as hexadecimal floats.
+The final-sum kernel stores the log-likelihoods straight into the engine's pinned host buffer instead of a device buffer
+that is then copied: a second child process with CRAB_NO_ZERO_COPY=1 must give the same values too."""
 import json
 import os
 import subprocess
@@ -51,10 +53,18 @@ def evaluate_all():
 def test_fused_mixture_launch_gives_the_bits_of_the_two_launches(gpu_engine_cls):
     assert "CRAB_NO_FUSED_MIX" not in os.environ
     fused = evaluate_all()
-    env = dict(os.environ, CRAB_NO_FUSED_MIX="1")
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stderr[-2000:]
-    two = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "CRAB_NO_ZERO_COPY" not in os.environ
+
+    def child(**switches):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, **switches), capture_output=True,
+                           text=True, timeout=60)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    two = child(CRAB_NO_FUSED_MIX="1")
+    assert fused == child(CRAB_NO_ZERO_COPY="1")
+    assert fused == child(CRAB_NO_ZERO_COPY="1", CRAB_NO_FUSED_MIX="1")
+    assert fused == evaluate_all()              # and again in this process: the host buffer is reused from call to call
     n_pat = [row["n_patterns"] for row in fused]
     assert sum(n <= 256 for n in n_pat) >= 4 and max(n_pat) > 256       # the fused form (every mixture mode) and the two launches
     assert fused == two
