@@ -10,6 +10,8 @@ The evaluator is injected, so the same plumbing runs over gloo on CPUs in the te
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 
@@ -55,18 +57,20 @@ def all_gather_doubles(vec, group=None, device=None) -> "np.ndarray":
         dev_recv = torch.empty(ws * n, dtype=torch.float64, device=device) if on_gpu else host_recv
         if len(_GATHER_BUFFERS) >= 64:    # payload sizes are few in practice (1, B, G); do not grow without bound
             _GATHER_BUFFERS.clear()
-        buf = _GATHER_BUFFERS[key] = (host_send, dev_send, dev_recv, host_recv)
-    host_send, dev_send, dev_recv, host_recv = buf
-    host_send.numpy()[:] = vec
+        buf = _GATHER_BUFFERS[key] = (host_send, dev_send, dev_recv, host_recv, host_send.numpy(), host_recv.numpy().reshape(ws, n))
+    host_send, dev_send, dev_recv, host_recv, send_np, recv_np = buf
+    send_np[:] = vec
     if dev_send is not host_send:
-        with torch.cuda.device(device):
+        # (one process per GPU: the rank's device is the current one already, and the switch is skipped)
+        here = device.index is None or torch.cuda.current_device() == device.index
+        with contextlib.nullcontext() if here else torch.cuda.device(device):
             dev_send.copy_(host_send, non_blocking=True)
             dist.all_gather_into_tensor(dev_recv, dev_send, group=group)
             host_recv.copy_(dev_recv, non_blocking=True)
             torch.cuda.current_stream().synchronize()
     else:
         dist.all_gather_into_tensor(dev_recv, dev_send, group=group)
-    return host_recv.numpy().reshape(ws, n).copy()
+    return recv_np.copy()
 
 
 def _single_rank(group) -> bool:
