@@ -2104,7 +2104,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     e->d_f.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_e.ensure((size_t)pl.K * e->n_pat_pad);
     e->d_patlnl.ensure((size_t)G * e->n_pat_pad);
-    e->d_partials.ensure((size_t)G * std::max(1, mix_blocks(e->n_pat)));
+    e->d_partials.ensure((size_t)G * std::max(1, mix_partials(e->n_pat)));
     e->d_lnL.ensure(G);
     if (pl.by_class) e->d_byclass.ensure((size_t)e->n_pat * pl.K + 1);
 

@@ -198,10 +198,11 @@ struct MixArgs {
     int64_t n_pat_pad;
     int32_t mode;
     double *pat_lnl;         // [n_groups][n_pat_pad] per-pattern log-likelihood
-    double *partials;        // [n_groups][mix_blocks(n_pat)]
+    double *partials;        // [n_groups][mix_partials(n_pat)]
     double *lnL;             // [n_groups]
 };
 int mix_blocks(int64_t n_pat);
+int mix_partials(int64_t n_pat);   // partial sums per group the mixture kernels may write
 void launch_mix(const MixArgs &a, hipStream_t stream);
 // out[p*K + k] = ln max(f, 1e-300) (clamp != 0) or ln f
 void launch_by_class(const double *f, const int32_t *e, int K, int64_t n_pat, int64_t n_pat_pad, int clamp, double *out,

@@ -1634,6 +1634,58 @@ __global__ __launch_bounds__(MIX_THREADS) void mix_final_kernel(MixArgs a, int n
     if (threadIdx.x == 0) a.lnL[grp] = s;
 }
 
+// The log-sum-exp mixture with one (pattern, class) per lane: 16 lanes per pattern, 16 patterns per workgroup.  mix_kernel gives
+// a lane one pattern and walks its K classes -- 2 K + 1 transcendental functions one after the other on the 9 947 lanes of
+// configs[1]; here a lane computes one log and one exponential, the maximum is taken across the 16 lanes (exact in any
+// order), and the exponentials are added in class order 0 .. K-1, as mix_kernel adds them: the per-pattern values are the
+// same bits.  The workgroup's 16 weighted terms are summed into one partial (16 times as many as mix_kernel's: the final
+// sum adds them in a different grouping, so the TOTAL differs from mix_kernel's in its last bits; it is as deterministic).
+constexpr int MIX_WIDE_PATTERNS = MIX_THREADS / 16;
+__global__ __launch_bounds__(MIX_THREADS) void mix_wide_kernel(MixArgs a)
+{
+    __shared__ double red[MIX_THREADS / 64];
+    __shared__ double lp[MIX_CACHED];
+    const size_t grp = blockIdx.y;
+    a.f += grp * a.K * a.n_pat_pad;
+    a.e += grp * a.K * a.n_pat_pad;
+    a.props += grp * a.K;
+    a.pat_lnl += grp * a.n_pat_pad;
+    a.partials += grp * gridDim.x;
+    if ((int)threadIdx.x < a.K) lp[threadIdx.x] = log(a.props[threadIdx.x]);
+    __syncthreads();
+    const int k = threadIdx.x & 15;
+    const long long p = (long long)blockIdx.x * MIX_WIDE_PATTERNS + (threadIdx.x >> 4);
+    const bool clamp = a.mode == MIX_LOGSUMEXP_CLAMP;
+    const bool live = p < a.n_pat && k < a.K;
+    double x = -__builtin_inf();
+    if (live) {
+        const size_t o = (size_t)k * a.n_pat_pad + p;
+        x = ln_site(a.f[o], a.e[o], clamp) + lp[k];
+    }
+    double mx = x;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const double o = __shfl_xor(mx, off, 16);
+        mx = o > mx ? o : mx;
+    }
+    const double t = live ? exp(x - mx) : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < MIX_CACHED; ++j) {
+        const double tj = __shfl(t, j, 16);
+        if (j < a.K) s += tj;
+    }
+    double contrib = 0.0;
+    if (k == 0 && p < a.n_pat) {
+        const double lnf = mx + log(s);
+        a.pat_lnl[p] = lnf;
+        const double wgt = a.weights[p];
+        contrib = wgt != 0.0 ? wgt * lnf : 0.0;
+    }
+    const double sum = block_sum(contrib, red);
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = sum;
+}
+
 // fixed-order final sum: one workgroup, strided partial sums then a tree
 __global__ __launch_bounds__(MIX_THREADS) void final_sum_kernel(const double *partials, int n, double *out)
 {
@@ -1647,6 +1699,7 @@ __global__ __launch_bounds__(MIX_THREADS) void final_sum_kernel(const double *pa
 }
 
 int mix_blocks(int64_t n_pat) { return (int)((n_pat + MIX_THREADS - 1) / MIX_THREADS); }
+int mix_partials(int64_t n_pat) { return (int)((n_pat + MIX_WIDE_PATTERNS - 1) / MIX_WIDE_PATTERNS); }   // the most any form writes
 
 void launch_mix(const MixArgs &a, hipStream_t stream)
 {
@@ -1656,6 +1709,15 @@ void launch_mix(const MixArgs &a, hipStream_t stream)
     static const bool no_fused = std::getenv("CRAB_NO_FUSED_MIX") != nullptr;   // A/B and the bit-identity test
     if (nb <= MIX_FUSED_BLOCKS && !no_fused) {
         hipLaunchKernelGGL(mix_final_kernel, dim3(ng), dim3(MIX_THREADS), 0, stream, a, nb);
+        return;
+    }
+    // log-sum-exp mixtures of up to 16 classes: one (pattern, class) per lane (6.5 us less per evaluation at configs[1] and at
+    // gene size, nothing at 45 000 patterns: profiles/r2_wide_mix_timing.txt); CRAB_NO_WIDE_MIX=1: one pattern per lane
+    static const bool wide = std::getenv("CRAB_NO_WIDE_MIX") == nullptr;
+    if (wide && a.mode != MIX_LINEAR && a.K <= MIX_CACHED) {
+        const int nw = mix_partials(a.n_pat);
+        hipLaunchKernelGGL(mix_wide_kernel, dim3(nw, ng), dim3(MIX_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(ng), dim3(MIX_THREADS), 0, stream, a.partials, nw, a.lnL);
         return;
     }
     hipLaunchKernelGGL(mix_kernel, dim3(nb, ng), dim3(MIX_THREADS), 0, stream, a);

@@ -1,8 +1,11 @@
-"""The end of an evaluation, two switches.  Kernel 3 with few patterns: mix_kernel + final_sum_kernel run as ONE launch (mix_final_kernel) when the patterns fit
-one block of 256.  The fused launch must give the bits of the two launches: the same evaluations are repeated in a
-child process with CRAB_NO_FUSED_MIX=1 (the switch is read once per process) and compared as hexadecimal floats.
-The final-sum kernel stores the log-likelihoods straight into the engine's pinned host buffer instead of a device buffer
-that is then copied: a second child process with CRAB_NO_ZERO_COPY=1 must give the same values too."""
+"""The end of an evaluation, three switches; each is read once per process, so the same evaluations are repeated in child
+processes and compared as hexadecimal floats.
+- With at most 256 patterns mix_kernel + final_sum_kernel run as ONE launch (mix_final_kernel), which must give the bits of
+  those two launches (CRAB_NO_FUSED_MIX=1 with CRAB_NO_WIDE_MIX=1).
+- The final-sum kernel stores the log-likelihoods straight into the engine's pinned host buffer instead of a device buffer
+  that is then copied: CRAB_NO_ZERO_COPY=1 must give the same bits.
+- Log-sum-exp mixtures of up to 16 classes run with one (pattern, class) per lane (mix_wide_kernel): every per-site value
+  must have the bits of the one-pattern-per-lane kernel; the totals are added in another grouping and agree to rounding."""
 import json
 import os
 import subprocess
@@ -53,7 +56,7 @@ def evaluate_all():
 def test_fused_mixture_launch_gives_the_bits_of_the_two_launches(gpu_engine_cls):
     assert "CRAB_NO_FUSED_MIX" not in os.environ
     fused = evaluate_all()
-    assert "CRAB_NO_ZERO_COPY" not in os.environ
+    assert "CRAB_NO_ZERO_COPY" not in os.environ and "CRAB_NO_WIDE_MIX" not in os.environ
 
     def child(**switches):
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, **switches), capture_output=True,
@@ -61,13 +64,26 @@ def test_fused_mixture_launch_gives_the_bits_of_the_two_launches(gpu_engine_cls)
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads(r.stdout.strip().splitlines()[-1])
 
-    two = child(CRAB_NO_FUSED_MIX="1")
-    assert fused == child(CRAB_NO_ZERO_COPY="1")
-    assert fused == child(CRAB_NO_ZERO_COPY="1", CRAB_NO_FUSED_MIX="1")
-    assert fused == evaluate_all()              # and again in this process: the host buffer is reused from call to call
+    def same_sites_close_totals(a, b):
+        for ra, rb in zip(a, b):
+            assert ra["n_patterns"] == rb["n_patterns"] and len(ra["hex"]) == len(rb["hex"])
+            if len(ra["hex"]) > 1:                                  # site-class rows end with 16 per-site values
+                assert ra["hex"][-16:] == rb["hex"][-16:]
+            for x, y in zip(ra["hex"], rb["hex"]):
+                x, y = float.fromhex(x), float.fromhex(y)
+                assert abs(x - y) <= 1e-14 * max(1.0, abs(x))
+
     n_pat = [row["n_patterns"] for row in fused]
     assert sum(n <= 256 for n in n_pat) >= 4 and max(n_pat) > 256       # the fused form (every mixture mode) and the two launches
-    assert fused == two
+    assert fused == child(CRAB_NO_ZERO_COPY="1")
+    assert fused == evaluate_all()              # and again in this process: the host buffer is reused from call to call
+    narrow = child(CRAB_NO_WIDE_MIX="1")
+    assert narrow == child(CRAB_NO_WIDE_MIX="1", CRAB_NO_FUSED_MIX="1") == child(CRAB_NO_WIDE_MIX="1", CRAB_NO_FUSED_MIX="1", CRAB_NO_ZERO_COPY="1")
+    same_sites_close_totals(fused, narrow)
+    same_sites_close_totals(fused, child(CRAB_NO_FUSED_MIX="1"))
+    for a, b in zip(fused, narrow):             # at most 256 patterns: the fused launch either way, the same bits
+        if a["n_patterns"] <= 256:
+            assert a == b
     for row in fused:
         assert all(np.isfinite(float.fromhex(h)) for h in row["hex"])
 
