@@ -19,4 +19,4 @@ for ra, rb in zip(a, b):
         worst = max(worst, abs(x - y) / max(1.0, abs(x)))
 print("per-site values: same bits; totals: largest relative difference %.2e" % worst)
 PY
-for i in 1 2; do for sh in "M8 30 400" "M8 100 10000" "M8 500 50000"; do timeout -k 10 200 CRAB_NO_WIDE_MIX=1 timeout -k 10 200 python3 scripts/gpu_time_c2.py $sh && timeout -k 10 200 python3 scripts/gpu_time_c2.py $sh || exit 1; done; done
+for i in 1 2; do for sh in "M8 30 400" "M8 100 10000" "M8 500 50000"; do CRAB_NO_WIDE_MIX=1 timeout -k 10 200 python3 scripts/gpu_time_c2.py $sh && timeout -k 10 200 python3 scripts/gpu_time_c2.py $sh || exit 1; done; done
