@@ -8,6 +8,8 @@
 //                       gathers prefetched under the products; sibling products are saved in register tiles;
 //                       power-of-two rescaling is fused; P operand images stream through LDS by LDS-DMA
 //   mix_kernel          per-pattern class mixture, log, pattern-weighted deterministic sum (per parameter vector)
+//   mix_wide_kernel     the same for log-sum-exp mixtures of up to 16 classes, one (pattern, class) per lane (the default there)
+//   mix_final_kernel    mixture and final sum in one launch when the patterns fit one block of 256
 //
 // fp64 MFMA shape: the pruning products use v_mfma_f64_4x4x4_4b_f64.  Measured on MI355X (scripts/micro/,
 // profiles/r1_micro_*): it sustains 73-76 TFLOP/s against 35-49 TFLOP/s for v_mfma_f64_16x16x4_f64, and its
