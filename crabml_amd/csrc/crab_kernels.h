@@ -168,6 +168,9 @@ struct PruneArgs {
     const uint8_t *codes_alt; // [n_rows][n_pat_pad] like codes
     const uint32_t *idx32;    // [n_clades][n_pat_pad]
     int32_t n_code_rows;      // rows of `codes`; 0 = no wide rows in this launch
+#ifdef CRAB_PROF
+    unsigned long long *prof; // diagnostic builds: per-wave phase counters (set by launch_prune), or nullptr
+#endif
 };
 // Stack slots the configured pruning kernel keeps in registers (the schedule must not park columns in the landing
 // tile of a product that pops a deeper, global-memory slot), and whether it has a prefetch tile at all.

@@ -460,7 +460,7 @@ constexpr bool PATH_OPS = true;
 template <int NT>
 struct Plan {
 #ifdef CRAB_PROF
-    static constexpr int CC = 96;  // the cycle counters need room: one register-resident stack slot less
+    static constexpr int CC = 96;  // the marks push the compiler a few registers past 64: one register-resident stack slot less
 #else
     static constexpr int CC = NT == 1 ? 64 : 96;  // registers the compiler may allocate
 #endif
@@ -788,15 +788,31 @@ __device__ __forceinline__ void gemm_tile(unsigned lds_addr, const R &ride)
 __device__ unsigned long long *g_clock_buf;
 #endif
 // Build with -DCRAB_PROF to get a per-phase cycle breakdown of the tree walk (s_memtime, summed per wave, printed by
-// launch_prune to stderr).  Diagnostic builds only: scripts/gpu_prof_phases.sh.
+// launch_prune to stderr).  Diagnostic builds only: scripts/gpu_prof_phases.sh.  The marks must cost the compiler next to
+// nothing: the twelve 64-bit counters of a wave are the 24 low lanes of ONE vector register (v_readlane / scalar add /
+// v_writelane) plus one 64-bit scalar for the last mark.  Even so the allocator ends up at v69 where the shipped build ends at
+// v63 (amdgpu_num_vgpr is a request: asking for 40 or 48 changes nothing), so this build gives the compiler 96 registers and
+// the walk one register-resident stack slot instead of two.  (Round 2 kept the counters in 26 scalar pairs; the compiler overran
+// even the 96 into the A-operand ring, and the first product's LDS reads overwrote spilled pointers: an illegal access in the
+// first launch.  scripts/check_reserved_vgprs.py -DCRAB_PROF sees exactly that, and runs as a test now.)
 #ifdef CRAB_PROF
+constexpr int PROF_N = 12;
+template <int I>
+__device__ __forceinline__ void prof_add(unsigned &acc, unsigned long long d)
+{
+    const unsigned long long sum = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)acc, 2 * I + 1) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)acc, 2 * I)) + d;
+    // (readfirstlane: the "s" operands must be provably wave-uniform for the compiler to put them in scalar registers)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sum), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sum >> 32));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(lo), "n"(2 * I));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(hi), "n"(2 * I + 1));
+}
 #define PROF_T(i)                                                   \
     {                                                               \
         const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-        w.prof_acc[i] += _t - w.prof_last;                          \
+        prof_add<i>(w.prof_acc, _t - w.prof_last);                  \
         w.prof_last = _t;                                           \
     }
-__device__ unsigned long long *g_prof_buf;
 #else
 #define PROF_T(i)
 #endif
@@ -826,7 +842,8 @@ struct Walk {
     char *save0;               // this wave's tile of save slot 0 (uniform), or nullptr; slot s is s * save_stride further
     size_t save_stride;
 #ifdef CRAB_PROF
-    unsigned long long prof_acc[12], prof_last;
+    unsigned prof_acc;              // lanes 2i, 2i + 1: this wave's counter i
+    unsigned long long prof_last;
 #endif
 };
 
@@ -1210,7 +1227,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     // to the 8 XCDs), so the workgroups sharing an L2 walk the same class's matrices at about the same time.
     // Placement only matters for speed: any mapping computes every item exactly once.
 #ifdef CRAB_PROF
-    unsigned long long prof_keep[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned prof_acc = 0;
 #endif
 #ifdef CRAB_CLOCK
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
@@ -1291,7 +1308,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.save0 = a.save ? a.save + (((size_t)save_cls * (size_t)n_tiles + (size_t)tile) * 4 + wave) * SAVE_TILE_BYTES : nullptr;
 
 #ifdef CRAB_PROF
-        for (int i = 0; i < 12; ++i) w.prof_acc[i] = prof_keep[i];
+        w.prof_acc = prof_acc;
         w.prof_last = __builtin_amdgcn_s_memtime();
 #endif
         int e0[NT], e1[NT];
@@ -1344,11 +1361,12 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         }
 #ifdef CRAB_PROF
         PROF_T(0)
-        for (int i = 0; i < 12; ++i) prof_keep[i] = w.prof_acc[i];
-        if (lane == 0)
-            for (int i = 0; i < 12; ++i) g_prof_buf[((size_t)blockIdx.x * 4 + wave) * 12 + i] = prof_keep[i];
+        prof_acc = w.prof_acc;
 #endif
     }
+#ifdef CRAB_PROF
+    if (a.prof && lane < 2 * PROF_N) ((unsigned *)a.prof)[((size_t)blockIdx.x * 4 + wave) * (2 * PROF_N) + lane] = prof_acc;
+#endif
 #ifdef CRAB_CLOCK
     if (lane == 0) {
         unsigned long long *cb = g_clock_buf + ((size_t)blockIdx.x * 4 + wave) * 4;
@@ -1426,19 +1444,26 @@ int prune_grid_size(int64_t n_work, int device)
 size_t prune_stack_doubles(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 16 * 64; }
 size_t prune_stack_ints(int grid, int max_depth) { return (size_t)grid * 4 * (max_depth > 0 ? max_depth : 1) * chosen_nt() * 64; }
 
-void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
+void launch_prune(const PruneArgs &args, int grid, hipStream_t stream)
 {
+    PruneArgs a = args;
     if (grid <= 0 || (a.n_ops <= 0 && !a.hdr)) return;
     const int nt = chosen_nt();
     const long long n_tiles = a.n_pat_pad / (64 * nt);
     const size_t lds = prune_lds_bytes();
 #ifdef CRAB_PROF
-    static unsigned long long *d_prof = nullptr;
-    if (!d_prof) {
-        (void)hipMalloc((void **)&d_prof, sizeof(unsigned long long) * 12 * 4 * 4096);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &d_prof, sizeof(d_prof));
+    // one counter buffer per device, handed to the kernel as an argument (a launch with no buffer writes nothing)
+    constexpr size_t prof_bytes = sizeof(unsigned long long) * PROF_N * 4 * 4096;
+    static unsigned long long *d_prof_dev[16] = {};
+    int prof_device = 0;
+    unsigned long long *d_prof = nullptr;
+    if (hipGetDevice(&prof_device) == hipSuccess && prof_device >= 0 && prof_device < 16 && grid <= 4096) {
+        if (!d_prof_dev[prof_device] && hipMalloc((void **)&d_prof_dev[prof_device], prof_bytes) != hipSuccess) d_prof_dev[prof_device] = nullptr;
+        d_prof = d_prof_dev[prof_device];
     }
-    (void)hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 12 * 4 * 4096, stream);
+    if (d_prof && hipMemsetAsync(d_prof, 0, prof_bytes, stream) != hipSuccess) d_prof = nullptr;
+    if (!d_prof) fprintf(stderr, "[crab prof] no counter buffer on device %d: this launch is not profiled\n", prof_device);
+    a.prof = d_prof;
 #endif
 #ifdef CRAB_CLOCK
     static unsigned long long *d_clock = nullptr;
@@ -1480,7 +1505,7 @@ void launch_prune(const PruneArgs &a, int grid, hipStream_t stream)
     }
 #endif
 #ifdef CRAB_PROF
-    {
+    if (d_prof) {
         (void)hipStreamSynchronize(stream);
         static const char *names[12] = {"prologue+root", "gemm wait vmcnt", "gemm barrier", "gemm dma issue + mfma", "gemm pop-mul",
                                         "leaf gather issue + wait", "leaf multiply", "normalise", "push", "late column issue + loop", "-", "op decode"};

@@ -11,7 +11,7 @@ LIMITS = {"prune_kernel_nt1": 64, "prune_kernel_nt2": 96}
 def violations(extra=()):
     limits = dict(LIMITS)
     if "-DCRAB_PROF" in extra:
-        limits["prune_kernel_nt1"] = 96
+        limits["prune_kernel_nt1"] = 96   # Plan<1>::CC of that build
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",

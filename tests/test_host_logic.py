@@ -319,6 +319,10 @@ def test_compiler_stays_out_of_the_fixed_tile_registers():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.violations() == []
+    # the diagnostic builds re-roll the allocation: the round-2 -DCRAB_PROF build overran its budget into the A-operand ring
+    # and faulted on the GPU (scripts/gpu_prof_phases.sh)
+    assert mod.violations(("-DCRAB_PROF",)) == []
+    assert mod.violations(("-DCRAB_CLOCK",)) == []
 
 
 def test_spectral_decomposition_of_every_fixture_matrix():
