@@ -421,6 +421,7 @@ struct ProgInfo {
     int n_ops = 0, first_gemm_op = -1, first_leaf_row = -1, first_leaf_op = -1, second_leaf_row = -1, third_leaf_row = -1;
     int second_leaf_op = -1, fourth_leaf_row = -1;   // a program that opens with two leaf edges of one node: see finalise_program
     int n_gemm = 0, n_leaf = 0;
+    bool cyclic = false;   // the program may run over consecutive tiles in one work item (F_NEXT_TILE, ROW_NEXT_TILE)
 };
 // A path program: what changes when only the branch above `node` moves (see build_path_program).
 struct PathProgram {
@@ -477,6 +478,8 @@ struct crab_engine : TreeProgram {
     struct CladeLaunch {                // one launch of clade programs (one level)
         int list_off = 0, n_entries = 0;      // its entries of the program list
         int64_t items_off = 0, n_items = 0;   // its work items
+        int grid = 0;                          // its workgroups ...
+        int64_t wg_off = 0;                    // ... and where their item ranges start in d_wg_begin (grid + 1 entries)
         int64_t bounds[9] = {0};
     };
     std::vector<CladeLaunch> dev_clade_launches;
@@ -500,7 +503,8 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_items;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_wg_begin;
+    DevBuf<ProgHdr> d_items;
     DevBuf<uint32_t> d_idx32;
     DevBuf<uint8_t> d_codes_alt;
     DevBuf<ProgHdr> d_hdr;
@@ -538,9 +542,9 @@ struct crab_engine : TreeProgram {
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_idx32.release(); d_codes_alt.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_wg_begin.release(); d_idx32.release(); d_codes_alt.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
-        h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release();
+        h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release(); d_eig_status.release(); h_eig_status.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (ev_k0) (void)hipEventDestroy(ev_k0);
@@ -583,7 +587,10 @@ uint64_t mix64(uint64_t h, uint64_t v);
 // ---------------------------------------------------------------------------------------------
 // Links the products of a program (a GEMM op's arg is the index of the next GEMM op, whose operand image it stages)
 // and lays down the leaf-edge prefetch schedule.  Used for the whole-tree program and for path programs alike.
-void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info)
+// `cyclic` (clade programs): the program is laid out to run over consecutive pattern tiles in one work item -- beyond its last
+// leaf edge the code queue continues with the first leaf edges of the next tile (ROW_NEXT_TILE), and the last product requests
+// their columns and stages the first product's operand image while it runs (F_NEXT_TILE).
+void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info, bool cyclic = false)
 {
     info = ProgInfo{};
     info.n_ops = (int)ops.size();
@@ -614,7 +621,14 @@ void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info)
         if (op.kind == OP_LEAF) leaf_ops.push_back(i);
     }
     const int n_leaf = (int)leaf_ops.size();
-    auto leaf_row = [&](int k) { return k < n_leaf ? ops[leaf_ops[k]].arg : -1; };
+    for (TreeOp &op : ops) op.flags &= ~F_NEXT_TILE;
+    // (cyclic needs a prefetch tile, a program that opens with a leaf edge and ends with a non-product op after its last product)
+    cyclic = cyclic && prune_has_prefetch() && n_leaf > 0 && leaf_ops[0] == 0 && info.n_gemm > 0 && ops.back().kind != OP_GEMM &&
+             ops.back().kind != OP_LEAF;
+    auto leaf_row = [&](int k) {
+        if (k < n_leaf) return ops[leaf_ops[k]].arg;
+        return cyclic && k - n_leaf < n_leaf ? (ops[leaf_ops[k - n_leaf]].arg | ROW_NEXT_TILE) : -1;
+    };
     info.first_leaf_row = leaf_row(0);
     info.second_leaf_row = leaf_row(1);
     info.third_leaf_row = leaf_row(2);
@@ -662,6 +676,39 @@ void finalise_program(std::vector<TreeOp> &ops, ProgInfo &info)
         } else if (req == 0 && next_is_leaf) {
             request_g(F_PRE_LATE);
         }
+    }
+    if (cyclic) {
+        int last_gemm = -1;
+        for (int i = 0; i < (int)ops.size(); ++i)
+            if (ops[i].kind == OP_GEMM) last_gemm = i;
+        // no leaf edge may follow the last product (its columns would still be queued when the tail wants the queue's head)
+        for (int i = last_gemm + 1; i < (int)ops.size(); ++i) cyclic = cyclic && ops[i].kind != OP_LEAF;
+        if (cyclic) {
+            // the last product asks for the next tile's head while it runs: the first leaf edge into the prefetch tile (free: no
+            // leaf edge follows), the second into its dying operand -- the landing tile of the tile that follows
+            TreeOp &lg = ops[last_gemm];
+            cyclic = !(lg.flags & (F_PRE_EARLY | F_PRE_DYING | F_POP_MUL | F_PUSH));
+            if (cyclic) {
+                lg.flags |= F_NEXT_TILE | F_PRE_EARLY;
+                lg.arg = info.first_gemm_op;
+                lg.pre_node = ops[leaf_ops[0]].node;
+                lg.pre_row2 = lg.pre_row3 = -1;
+                if (info.second_leaf_op == 1) {
+                    lg.flags |= F_PRE_DYING;
+                    lg.pre_node_b = ops[1].node;
+                }
+                info.cyclic = true;
+            }
+        }
+    }
+    if (!info.cyclic && n_leaf > 0) {   // (rows of a next tile were handed out above: take them back)
+        for (TreeOp &op : ops) {
+            if (op.pre_row2 >= 0 && (op.pre_row2 & ROW_NEXT_TILE)) op.pre_row2 = -1;
+            if (op.pre_row3 >= 0 && (op.pre_row3 & ROW_NEXT_TILE)) op.pre_row3 = -1;
+        }
+        if (info.second_leaf_row >= 0 && (info.second_leaf_row & ROW_NEXT_TILE)) info.second_leaf_row = -1;
+        if (info.third_leaf_row >= 0 && (info.third_leaf_row & ROW_NEXT_TILE)) info.third_leaf_row = -1;
+        if (info.fourth_leaf_row >= 0 && (info.fourth_leaf_row & ROW_NEXT_TILE)) info.fourth_leaf_row = -1;
     }
 }
 
@@ -1270,7 +1317,7 @@ void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows,
         st.arg = j;
         st.pre_node = st.pre_node_b = st.pre_row2 = st.pre_row3 = -1;
         cl.prog.ops.push_back(st);
-        finalise_program(cl.prog.ops, cl.prog.info);
+        finalise_program(cl.prog.ops, cl.prog.info, true);
     }
     rewrite(0, (int)ops.size() - 1, -1, ct.main.ops);
     finalise_program(ct.main.ops, ct.main.info);
@@ -1885,7 +1932,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         int n_first = 0, first_off = 0;
         e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
         e->dev_gemm_extra = 0;
-        std::vector<int32_t> items;                 // launch 1 of clade tables: (list entry, tile) per work item
+        struct ItemRef {
+            int32_t prog, tile0, n;
+        };
+        std::vector<ItemRef> items;                 // clade launches: (program, first tile, tiles) per work item
+        std::vector<int32_t> wg_begin;              // ... and per launch, which items each workgroup walks (grid + 1 entries)
         if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
@@ -1947,36 +1998,74 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                 for (int l = 0; l < ct.n_levels; ++l) {
                     crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
                     cl.list_off = (int)lists.size();
-                    cl.items_off = (int64_t)items.size() / 2;
+                    cl.items_off = (int64_t)items.size();
                     std::vector<int> order;
                     for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
                     std::stable_sort(order.begin(), order.end(),
                                      [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
-                    std::vector<double> item_w;
+                    // Work items: runs of consecutive tiles of one (class, clade) -- a cyclic program pays its prologue (item ->
+                    // header -> ops, codes -> columns -> operand image: a chain of dependent loads, ~9 us) once per item, later
+                    // tiles start from what the previous tile's tail requested.  Runs are as long as the launch can afford while it
+                    // still has ~3 items per resident workgroup (CRAB_CLADE_ITEM_TILES sets the length instead; 1 = one tile per item).
+                    int64_t level_tiles = 0;
+                    for (int j : order) level_tiles += ct.clades[j].tiles;
+                    const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device);
+                    int64_t run_len = std::max<int64_t>(1, std::min<int64_t>(8, level_tiles * n_tab / (3 * slots)));
+                    if (const char *sv = std::getenv("CRAB_CLADE_ITEM_TILES")) run_len = std::max(1, std::min(64, std::atoi(sv)));
+                    struct Item {
+                        int32_t prog, tile0, n;
+                        double w;
+                    };
+                    std::vector<Item> its;
                     for (int t = 0; t < n_tab; ++t)
                         for (int j : order) {
-                            const int entry = (int)lists.size() - cl.list_off;
                             lists.push_back(pl.K + t * n_cl + j);
                             const ProgInfo &in = ct.clades[j].prog.info;
-                            for (int64_t tl = 0; tl < ct.clades[j].tiles; ++tl) {
-                                items.push_back(entry);
-                                items.push_back((int32_t)tl);
-                                item_w.push_back(1.0 + in.n_gemm + 0.1 * (in.n_ops - in.n_gemm));
+                            const int64_t tiles = ct.clades[j].tiles;
+                            const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
+                            for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
+                                const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
+                                its.push_back({(int32_t)(pl.K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo),
+                                               1.0 + (double)(hi - lo) * (in.n_gemm + 0.1 * (in.n_ops - in.n_gemm))});
                             }
-                            e->dev_gemm_extra += (int64_t)in.n_gemm * ct.clades[j].tiles * prune_tile_width();
+                            e->dev_gemm_extra += (int64_t)in.n_gemm * tiles * prune_tile_width();
                         }
                     cl.n_entries = (int)lists.size() - cl.list_off;
-                    cl.n_items = (int64_t)item_w.size();
-                    // one chunk of the launch's items per XCD, of equal work
+                    cl.n_items = (int64_t)its.size();
+                    // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that share
+                    // an L2 walk the same matrices).  Inside a chunk the items are assigned to the XCD's workgroups longest first,
+                    // each to the workgroup with the least work so far; a workgroup walks its items in the original order.
                     double total = 0.0, acc = 0.0;
-                    for (double w : item_w) total += w;
+                    for (const Item &it : its) total += it.w;
                     int x = 1;
                     cl.bounds[0] = 0;
-                    for (size_t i = 0; i < item_w.size() && x < 8; ++i) {
-                        acc += item_w[i];
+                    for (size_t i = 0; i < its.size() && x < 8; ++i) {
+                        acc += its[i].w;
                         while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
                     }
-                    while (x <= 8) cl.bounds[x++] = (int64_t)item_w.size();
+                    while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
+                    cl.grid = prune_grid_size((int64_t)its.size(), e->device);
+                    const int per_xcd = cl.grid / 8;
+                    std::vector<std::vector<int>> of_wg(cl.grid);
+                    for (int c8 = 0; c8 < 8 && per_xcd > 0; ++c8) {
+                        std::vector<int> by_w;
+                        for (int64_t i = cl.bounds[c8]; i < cl.bounds[c8 + 1]; ++i) by_w.push_back((int)i);
+                        std::stable_sort(by_w.begin(), by_w.end(), [&](int p, int q) { return its[p].w > its[q].w; });
+                        std::vector<double> load(per_xcd, 0.0);
+                        for (int i : by_w) {
+                            const int j = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                            load[j] += its[i].w;
+                            of_wg[j * 8 + c8].push_back(i);
+                        }
+                    }
+                    cl.wg_off = (int64_t)wg_begin.size();
+                    int32_t n_out = 0;
+                    for (int b = 0; b < cl.grid; ++b) {
+                        wg_begin.push_back(n_out);
+                        std::sort(of_wg[b].begin(), of_wg[b].end());
+                        for (int i : of_wg[b]) items.push_back({its[i].prog, its[i].tile0, its[i].n}), ++n_out;
+                    }
+                    wg_begin.push_back(n_out);
                 }
             }
             first_off = (int)lists.size();
@@ -2051,9 +2140,18 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         e->dev_clades = use_clades;
         e->dev_tabled = tabled;
         e->dev_first_off = first_off;
-        e->d_items.ensure(items.size() + 2);
-        if (!items.empty())
-            HIP_CHECK(hipMemcpyAsync(e->d_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        // an item record = its program's header + (program, first tile, tiles): one scalar load per item on the device
+        std::vector<ProgHdr> item_recs(items.size());
+        for (size_t i = 0; i < items.size(); ++i) {
+            item_recs[i] = hdrs[items[i].prog];
+            item_recs[i].prog = items[i].prog, item_recs[i].tile0 = items[i].tile0, item_recs[i].item_tiles = items[i].n;
+        }
+        e->d_wg_begin.ensure(wg_begin.size() + 1);
+        if (!wg_begin.empty())
+            HIP_CHECK(hipMemcpyAsync(e->d_wg_begin.p, wg_begin.data(), wg_begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        e->d_items.ensure(item_recs.size() + 1);
+        if (!item_recs.empty())
+            HIP_CHECK(hipMemcpyAsync(e->d_items.p, item_recs.data(), item_recs.size() * sizeof(ProgHdr), hipMemcpyHostToDevice, e->stream));
         e->dev_pidx = *pidx;
         e->dev_vec_node = vec_node;
         e->dev_part_target = part_target;
@@ -2158,12 +2256,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             const crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
             pc.K = cl.n_entries;
             pc.cls_list = e->d_cls.p + cl.list_off;
-            pc.items = e->d_items.p + 2 * cl.items_off;
+            pc.items = e->d_items.p + cl.items_off;
             pc.n_items = cl.n_items;
             pc.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
             pc.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
             std::copy(cl.bounds, cl.bounds + 9, pc.xcd_bounds);
-            launch_prune(pc, prune_grid_size(cl.n_items, e->device), e->stream);
+            pc.wg_begin = e->d_wg_begin.p + cl.wg_off;
+            launch_prune(pc, cl.grid, e->stream);
         }
         // the main programs (among the first launch's) read the outermost clades' tables through the last block of wide rows
         pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
@@ -2174,7 +2273,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         pa.K = n_second;
         pa.cls_list = e->d_cls.p + e->dev_first_off + n_first;
         std::copy(e->dev_bounds_second, e->dev_bounds_second + 9, pa.xcd_bounds);
-        launch_prune(pa, grid_second, e->stream);
+            launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 

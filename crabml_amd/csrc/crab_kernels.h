@@ -63,10 +63,19 @@ enum : int32_t {
     // the root, on tiles the base vector's walk left in HBM): see "save area" below
     F_POP_SAVED = 512,  // GEMM with F_POP_MUL (path programs): the saved product is save slot `slot`, not stack slot `slot`
     F_SAVE = 1024,      // GEMM (base vector's program): store this edge's tiles in save slots sv, sv+1, sv+2
-    F_TABLE = 2048      // OP_LOAD with F_SAVE (clade programs): the current tile, its exponents folded in, becomes 16 columns of the
+    F_TABLE = 2048,     // OP_LOAD with F_SAVE (clade programs): the current tile, its exponents folded in, becomes 16 columns of the
                         // clade's table (a gather image of as many columns as the clade shows distinct sub-patterns), at matrix `mat`
+    // work items of several pattern tiles (clade programs: the same short program over the clade's consecutive tiles).  The
+    // program is cyclic: its tail requests what the next tile's head consumes, so tiles after the first have no prologue.
+    F_NEXT_TILE = 4096  // on the last GEMM: its requests (F_PRE_EARLY: matrix pre_mat into the prefetch tile; F_PRE_DYING: pre_mat_b
+                        // into the dying operand, the landing tile from then on) are the first leaf edges of the item's NEXT tile,
+                        // read with that tile's codes, which the code queue holds by then (rows with ROW_NEXT_TILE), and `arg` is
+                        // the FIRST product's matrix; all three only if another tile follows
 };
-constexpr int OP_FLAG_BITS = 12;   // DevOp::w0 = kind | flags << 2 | slot << (2 + OP_FLAG_BITS)
+constexpr int OP_FLAG_BITS = 13;   // DevOp::w0 = kind | flags << 2 | slot << (2 + OP_FLAG_BITS)
+// A code-queue row (ProgHdr::*_leaf_row, DevOp::pre_row2/3) with this bit set is a row of the NEXT tile of the work item: read 64
+// patterns further on, or not at all if the item has no further tile.
+constexpr int32_t ROW_NEXT_TILE = 1 << 30;
 // The host keeps one topology-only program (TreeOp, node ids) and resolves it per site class into the packed
 // device form (DevOp, matrix indices) before upload, so the kernel never chases the (class, node) -> matrix table.
 struct TreeOp {
@@ -103,7 +112,13 @@ struct alignas(16) ProgHdr {
                                               // the operand image and requests the columns without reading the ops first
     int32_t second_leaf_mat;   // >= 0: the program opens with two leaf edges of one node and this is the second one's matrix -- the
     int32_t fourth_leaf_row;   // prologue requests its columns into the landing tile; the code queue then continues at this row
+    // A work item of a launch with an item list (PruneArgs::items) is a copy of its program's header with these three filled in:
+    // one 64-byte scalar load stands between an item's number and everything its prologue needs.
+    int32_t prog;              // the program (row of `ops`, of `hdr` and of out_f)
+    int32_t tile0;             // first pattern tile
+    int32_t item_tiles;        // consecutive tiles the item walks (> 1 only for programs with F_NEXT_TILE)
 };
+static_assert(sizeof(ProgHdr) == 64, "an item record is one s_load_dwordx16");
 // Save area.  The base vector's walk stores, for every internal edge c (GEMM op with F_SAVE): slot sv = L_c, the operand
 // of the edge's product; slot sv+1 = the parent's running product after this op (unless the op completes the parent);
 // slot sv+2 = the edge's message P_c L_c before it is multiplied into the running product (if the op has F_POP_MUL).
@@ -163,11 +178,13 @@ struct PruneArgs {
     // sub-pattern by a clade program (launch 1, codes_alt, work items from `items`); the message of its root's branch lands in a
     // table laid out like a gather image of U columns, and the main program reads it like a leaf edge: alignment rows >=
     // n_code_rows are rows of idx32 (per pattern: the column of its sub-pattern) instead of byte codes.
-    const int32_t *items;     // [n_items][2] (entry of cls_list, pattern tile) per work item, or nullptr: entry-major, every tile
+    const ProgHdr *items;     // [n_items] work items (ProgHdr::prog, tile0, item_tiles), or nullptr: the programs of cls_list in
+                              // order, every tile, one tile per item
     int64_t n_items;
     const uint8_t *codes_alt; // [n_rows][n_pat_pad] like codes
     const uint32_t *idx32;    // [n_clades][n_pat_pad]
     int32_t n_code_rows;      // rows of `codes`; 0 = no wide rows in this launch
+    const int32_t *wg_begin;  // with items: workgroup b walks items [wg_begin[b], wg_begin[b + 1]) (grid + 1 entries), or nullptr
 #ifdef CRAB_PROF
     unsigned long long *prof; // diagnostic builds: per-wave phase counters (set by launch_prune), or nullptr
 #endif

@@ -32,6 +32,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+// Host-written tables the kernels only read (item records, headers, program lists), through the constant address space: a
+// wave-uniform read is then a scalar load whatever the alias analysis makes of the kernel's own stores and atomics.
+#define CONST_PTR(T, p) ((const __attribute__((address_space(4))) T *)(unsigned long long)(p))
 
 
 // =============================================================================================
@@ -538,6 +541,15 @@ __device__ __forceinline__ void r_gstore128(void *sbase, unsigned voff)
 {
     asm volatile("global_store_dwordx4 %2, v[%0:%1], %3 offset:%4" ::"n"(S), "n"(S + 3), "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+// A wave-uniform pointer, provably so: the "s" operands of the loads and stores above must come out in scalar registers
+// whatever the divergence analysis makes of the loops around them (folds away when the value is in scalar registers already).
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- tile-wide operations ----
@@ -827,12 +839,12 @@ struct Walk {
     int buf;                   // LDS buffer holding the operand image of the next product
     unsigned code_off[NT];     // code queue: byte offset of the column inside a gather image, per pattern group, for
     unsigned code_off2[NT];    //   the next leaf edge whose columns are not requested yet, and the one after it
-    const uint8_t *codes;      // this lane's column of the code table
-    const uint32_t *idx;       // this lane's column of the wide rows (clade tables), or nullptr
+    const uint8_t *codes;      // the code table this program reads (wave-uniform: per-lane state is kept to 32-bit offsets, the
+    unsigned pat;              //   compiler's registers are few); this lane's pattern in group 0 = its column there and in idx32
     size_t table_off;          // this wave's 16 columns inside a clade table: (tile * 4 + wave) * 8192 bytes
     const char *gather0;       // gather image of matrix 0
     char *stack;               // this wave's stack area (uniform) ...
-    int32_t *stack_e;          // ... and this lane's element of its exponent area
+    int32_t *stack_e;          // ... and its exponent area (uniform; this lane's element is [lane])
     int estk[3][NT];           // exponents of the register-resident stack slots (first NSTK used)
     unsigned stack_voff;       // this lane's byte offset inside a saved tile: (lane & 15) * 512 + (lane >> 4) * 16
     unsigned lds_a;            // LDS byte address of this lane's A operand inside a tile pair
@@ -841,37 +853,54 @@ struct Walk {
     int n_ops;                 // length of this program
     char *save0;               // this wave's tile of save slot 0 (uniform), or nullptr; slot s is s * save_stride further
     size_t save_stride;
+    bool more;                 // the work item has another tile after this one (F_NEXT_TILE, ROW_NEXT_TILE)
 #ifdef CRAB_PROF
     unsigned prof_acc;              // lanes 2i, 2i + 1: this wave's counter i
     unsigned long long prof_last;
 #endif
 };
 
+// A header or item record through the constant address space (sixteen scalar dwords).
+__device__ __forceinline__ ProgHdr load_hdr(const ProgHdr *p)
+{
+    ProgHdr h;
+    const auto *src = CONST_PTR(int32_t, p);
+    int32_t *dst = reinterpret_cast<int32_t *>(&h);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ProgHdr) / 4); ++i) dst[i] = src[i];
+    return h;
+}
 // Byte offset, inside a gather image, of this lane's share of the column its pattern shows in alignment row `row`.
 template <int NT>
 __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, unsigned (&off)[NT])
 {
     unsigned code[NT];
+    size_t adv = 0;
+    if (row & ROW_NEXT_TILE) {   // the same row, one tile on (wave-uniform)
+        if (!w.more) return;
+        row &= ~ROW_NEXT_TILE;
+        adv = 64 * NT;
+    }
     if (w.a.n_code_rows > 0 && row >= w.a.n_code_rows) {   // a clade's table: the column of this pattern's sub-pattern (wave-uniform branch)
-        const uint32_t *r = w.idx + (size_t)(row - w.a.n_code_rows) * w.a.n_pat_pad;
+        const uint32_t *r = w.a.idx32 + (size_t)(row - w.a.n_code_rows) * w.a.n_pat_pad + adv;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #ifdef CRAB_ABLATE_CODES
             code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
             (void)r;
 #else
-            code[nt] = r[nt * 16];
+            code[nt] = r[w.pat + nt * 16];
 #endif
         }
     } else {
-        const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad;
+        const uint8_t *r = w.codes + (size_t)row * w.a.n_pat_pad + adv;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #ifdef CRAB_ABLATE_CODES   // timing experiment only (wrong results): no load, so no wait for one either
             code[nt] = (unsigned)(row + (w.lane & 15) + nt) % 61u;
             (void)r;
 #else
-            code[nt] = r[nt * 16];
+            code[nt] = r[w.pat + nt * 16];
 #endif
         }
     }
@@ -906,7 +935,7 @@ template <int NT, int D>
 __device__ __forceinline__ void issue_columns(Walk<NT> &w, int mat)
 {
     // (readfirstlane: the "s" operand of the loads must be provably wave-uniform)
-    const char *img = w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8);
+    const char *img = uniform_ptr(w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8));
     using S8 = std::make_integer_sequence<int, 8>;
 #ifdef CRAB_ABLATE_GATHER
     (void)img;
@@ -955,10 +984,10 @@ __device__ __forceinline__ void push(Walk<NT> &w, int slot, const int (&eX)[NT])
             for (int nt = 0; nt < NT; ++nt) w.estk[2][nt] = eX[nt];
             return;
         }
-    int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+    int32_t *se = w.stack_e + (size_t)slot * (NT * 64) + w.lane;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) se[nt * 64] = eX[nt];
-    t_store<NT, X>(w.stack + (size_t)slot * slot_bytes, w.stack_voff);
+    t_store<NT, X>(uniform_ptr(w.stack + (size_t)slot * slot_bytes), w.stack_voff);
 }
 // Y *= stack[slot]; the dead tile L is the landing zone when the slot is in global memory.
 template <int NT, int Y, int L>
@@ -987,11 +1016,11 @@ __device__ __forceinline__ void pop_mul(Walk<NT> &w, int slot, int (&eY)[NT])
             for (int nt = 0; nt < NT; ++nt) eY[nt] += w.estk[2][nt];
             return;
         }
-    const int32_t *se = w.stack_e + (size_t)slot * (NT * 64);
+    const int32_t *se = w.stack_e + (size_t)slot * (NT * 64) + w.lane;
     int es[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) es[nt] = se[nt * 64];
-    t_load<NT, L>(w.stack + (size_t)slot * slot_bytes, w.stack_voff);
+    t_load<NT, L>(uniform_ptr(w.stack + (size_t)slot * slot_bytes), w.stack_voff);
     r_wait_vm0();
     t_mul<NT, Y, L>();
 #pragma unroll
@@ -1003,7 +1032,7 @@ template <int NT, int X>
 __device__ __forceinline__ void save_tile(Walk<NT> &w, int slot, const int (&eX)[NT])
 {
     static_assert(NT == 1, "path programs are built for the 64-pattern kernel only");
-    char *dst = w.save0 + (size_t)slot * w.save_stride;
+    char *dst = uniform_ptr(w.save0 + (size_t)slot * w.save_stride);
     ((int32_t *)(dst + 16 * 64 * 8))[w.lane] = eX[0];
     t_store<NT, X>(dst, w.stack_voff);
 }
@@ -1011,7 +1040,7 @@ template <int NT, int D>
 __device__ __forceinline__ void load_saved(Walk<NT> &w, int slot, int (&es)[NT])
 {
     static_assert(NT == 1, "path programs are built for the 64-pattern kernel only");
-    const char *src = w.save0 + (size_t)slot * w.save_stride;
+    const char *src = uniform_ptr(w.save0 + (size_t)slot * w.save_stride);
     es[0] = ((const int32_t *)(src + 16 * 64 * 8))[w.lane];
     t_load<NT, D>(src, w.stack_voff);
     r_wait_vm0();
@@ -1028,7 +1057,11 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
     constexpr int G = Plan<NT>::G;
     const PruneArgs &a = w.a;
 
-    while (w.ip < w.n_ops) {
+    for (;;) {
+        // (readfirstlane: the op counter is wave-uniform, and the compiler must know it -- it once took it for divergent and
+        // decoded every field of every op in a waterfall loop)
+        w.ip = __builtin_amdgcn_readfirstlane(w.ip);
+        if (w.ip >= w.n_ops) break;
         PROF_T(9)
         const int il = w.ip & 63;
         if (il == 0 && w.ip > 0) w.batch = w.ops[w.ip + w.lane];
@@ -1058,12 +1091,16 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
             if constexpr (NT == 1 && PATH_OPS)
                 if (flags & F_SAVE) save_tile<NT, X>(w, sv, eX);   // the operand of this edge's product
             Ride<(PRE ? G : -1), X> ride;
-            ride.dma_src = arg >= 0 ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
+            // (on the last product of a cyclic program the two column requests are the head of the item's next tile and the image
+            // it stages is the first product's: all three only if there is such a tile)
+            const bool pre_ok = !(flags & F_NEXT_TILE) || w.more;
+            const bool stage = arg >= 0 && pre_ok;
+            ride.dma_src = stage ? (const char *)(a.P + (size_t)arg * P_ELEMS) + w.wave * 8192 + w.lane * 16 : nullptr;
             ride.dma_dst = w.smem + (w.buf ^ 1) * 32768 + w.wave * 8192;
-            const bool pre_g = PRE && (flags & F_PRE_EARLY), pre_b = PRE && (flags & F_PRE_DYING);
-            ride.img = pre_g ? w.gather0 + (size_t)pre_mat * (P_ELEMS * 8) : nullptr;
+            const bool pre_g = PRE && (flags & F_PRE_EARLY) && pre_ok, pre_b = PRE && (flags & F_PRE_DYING) && pre_ok;
+            ride.img = uniform_ptr(pre_g ? w.gather0 + (size_t)pre_mat * (P_ELEMS * 8) : nullptr);
             ride.voff = w.code_off[0];
-            ride.img_b = pre_b ? w.gather0 + (size_t)pre_mat_b * (P_ELEMS * 8) : nullptr;
+            ride.img_b = uniform_ptr(pre_b ? w.gather0 + (size_t)pre_mat_b * (P_ELEMS * 8) : nullptr);
             ride.voff_b = pre_g ? w.code_off2[0] : w.code_off[0];
             // Outside a product a wave is on its latency-bound critical path (gathers, multiplies, barriers) while
             // the other wave of the SIMD feeds the MFMA pipe: give that path the issue priority (measured +2 %).
@@ -1151,7 +1188,7 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
                     ex = ex < -1022 ? -1022 : ex > 1023 ? 1023 : ex;
                     t_scale_seq<X>(__hiloint2double((1023 + ex) << 20, 0), std::make_integer_sequence<int, 16>{});
 #ifndef CRAB_ABLATE_TABLE_STORE   // (CRAB_ABLATE_*: timing experiments with wrong results, scripts/gpu_ablate.sh)
-                    t_store<NT, X>((char *)w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8) + w.table_off, w.stack_voff);
+                    t_store<NT, X>(uniform_ptr((char *)w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8) + w.table_off), w.stack_voff);
 #endif
                 } else if (flags & F_SAVE) {
                     save_tile<NT, X>(w, sv, eX);
@@ -1174,34 +1211,55 @@ __device__ __forceinline__ bool walk(Walk<NT> &w, int (&eX)[NT], int (&eY)[NT])
         PROF_T(7)
         if (flags & F_PUSH) push<NT, X>(w, slot, eX);
         PROF_T(8)
-        if constexpr (PRE)
+        if constexpr (PRE) {
             if (flags & F_PRE_LATE) {
                 issue_columns<NT, G>(w, pre_mat);
                 refill_codes1<NT>(w, pre_row2);
             }
+        }
     }
     return true;
 }
 
+// four terms of the root sum: states 4 (4C + i) + g, i = 0..3, for every pattern group
+template <int NT, int X, int C>
+__device__ __forceinline__ void root_dot4(const double *pi_g, double (&f)[NT])
+{
+    double m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = pi_g[4 * (4 * C + i)];
+    r_fma_into<X + 2 * (4 * C + 0)>(f[0], m[0]);
+    r_fma_into<X + 2 * (4 * C + 1)>(f[0], m[1]);
+    r_fma_into<X + 2 * (4 * C + 2)>(f[0], m[2]);
+    r_fma_into<X + 2 * (4 * C + 3)>(f[0], m[3]);
+    if constexpr (NT == 2) {
+        r_fma_into<X + 32 + 2 * (4 * C + 0)>(f[1], m[0]);
+        r_fma_into<X + 32 + 2 * (4 * C + 1)>(f[1], m[1]);
+        r_fma_into<X + 32 + 2 * (4 * C + 2)>(f[1], m[2]);
+        r_fma_into<X + 32 + 2 * (4 * C + 3)>(f[1], m[3]);
+    }
+}
 // root: f = sum_i pi_i L_root[i]   (likelihood.rs:236-243)
 template <int NT, int X>
-__device__ __forceinline__ void root_sum(const PruneArgs &a, const int (&eX)[NT], size_t out0, int g)
+__device__ __forceinline__ void root_sum(const PruneArgs &a, const int (&eX)[NT], size_t out_row, unsigned pat, int g)
 {
-    double pi[16];
+    // pi in four pieces of four: the walk's per-lane state is still live here when the item has another tile, and sixteen
+    // doubles at once would push the compiler past its 64 registers (same multiply-adds in the same order)
+    double f_[NT];
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) pi[idx] = a.pi_pad[4 * idx + g];
+    for (int nt = 0; nt < NT; ++nt) f_[nt] = 0.0;
+    root_dot4<NT, X, 0>(a.pi_pad + g, f_);
+    root_dot4<NT, X, 1>(a.pi_pad + g, f_);
+    root_dot4<NT, X, 2>(a.pi_pad + g, f_);
+    root_dot4<NT, X, 3>(a.pi_pad + g, f_);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        double f = 0.0;
-        if (nt == 0)
-            t_dot_seq<X>(f, pi, std::make_integer_sequence<int, 16>{});
-        else
-            t_dot_seq<X + 32>(f, pi, std::make_integer_sequence<int, 16>{});
+        double f = f_[nt];
         f += __shfl_xor(f, 16);
         f += __shfl_xor(f, 32);
         if (g == 0) {
-            a.out_f[out0 + nt * 16] = f;
-            a.out_e[out0 + nt * 16] = eX[nt];
+            a.out_f[out_row + pat + nt * 16] = f;
+            a.out_e[out_row + pat + nt * 16] = eX[nt];
         }
     }
 }
@@ -1235,46 +1293,37 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
     const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
-    // An item is found by two dependent scalar loads (item list -> program list) before its header can be read.  Launches of
-    // short programs (clade programs, tree parts, path programs) run a dozen items per workgroup: the next item's program and
-    // tile are looked up before the current item's walk, so that its prologue starts one load away from its data.  (The header
-    // itself is not carried across the walk: the eleven scalar registers it takes push the compiler out of its register budget.)
-    struct ItemDesc {
-        int cls;
-        int tile;
-    };
-    auto locate = [&](long long wi) {
-        ItemDesc d;
-        int ci;
-        if (a.items) {
-            ci = a.items[2 * wi], d.tile = a.items[2 * wi + 1];
-        } else {
-            ci = (int)(wi / n_tiles);
-            d.tile = (int)(wi - (long long)ci * n_tiles);
-        }
-        d.cls = a.cls_list ? a.cls_list[ci] : ci;
-        return d;
-    };
-    ItemDesc next_item{0, 0};
-    if (chunk_lo + xj < chunk_hi) next_item = locate(chunk_lo + xj);
-    for (long long wi = chunk_lo + xj; wi < chunk_hi; wi += per_xcd) {
+    // A launch with an item list says which items each workgroup walks (wg_begin: the host balances the predicted work of
+    // the workgroups of an XCD over that XCD's chunk); otherwise a chunk's items are dealt round-robin to its workgroups.
+    long long wi_first = chunk_lo + xj, wi_end = chunk_hi, wi_step = per_xcd;
+    if (a.items && a.wg_begin) wi_first = a.wg_begin[blockIdx.x], wi_end = a.wg_begin[blockIdx.x + 1], wi_step = 1;
+    for (long long wi = wi_first; wi < wi_end; wi += wi_step) {
         struct {
             int cls;
             long long tile;
             ProgHdr h;
         } item;
-        item.cls = next_item.cls, item.tile = next_item.tile;
-        if (a.hdr) {
-            item.h = a.hdr[item.cls];
+        int item_tiles = 1;
+        if (a.items) {   // one scalar load: the program's header, the tile and the number of tiles
+            item.h = load_hdr(a.items + wi);
+            item.cls = item.h.prog, item.tile = item.h.tile0;
+            item_tiles = __builtin_amdgcn_readfirstlane(item.h.item_tiles);   // (provably wave-uniform: it bounds the tile loop)
         } else {
-            item.h.n_ops = a.n_ops, item.h.first_gemm_op = a.first_gemm_op, item.h.first_leaf_row = a.first_leaf_row;
-            item.h.first_leaf_op = a.first_leaf_op, item.h.second_leaf_row = a.second_leaf_row, item.h.third_leaf_row = a.third_leaf_row;
-            item.h.save_cls = item.cls, item.h.no_root = 0, item.h.alt_codes = 0, item.h.first_gemm_mat = -2, item.h.first_leaf_mat = -2;
-            item.h.second_leaf_mat = a.second_leaf_op >= 0 ? -2 : -1, item.h.fourth_leaf_row = a.fourth_leaf_row;
+            const int ci = (int)(wi / n_tiles);
+            item.tile = wi - (long long)ci * n_tiles;
+            item.cls = a.cls_list ? CONST_PTR(int32_t, a.cls_list)[ci] : ci;
+            if (a.hdr) {
+                item.h = load_hdr(a.hdr + item.cls);
+            } else {
+                item.h.n_ops = a.n_ops, item.h.first_gemm_op = a.first_gemm_op, item.h.first_leaf_row = a.first_leaf_row;
+                item.h.first_leaf_op = a.first_leaf_op, item.h.second_leaf_row = a.second_leaf_row, item.h.third_leaf_row = a.third_leaf_row;
+                item.h.save_cls = item.cls, item.h.no_root = 0, item.h.alt_codes = 0, item.h.first_gemm_mat = -2, item.h.first_leaf_mat = -2;
+                item.h.second_leaf_mat = a.second_leaf_op >= 0 ? -2 : -1, item.h.fourth_leaf_row = a.fourth_leaf_row;
+            }
         }
-        if (wi + per_xcd < chunk_hi) next_item = locate(wi + per_xcd);
         const long long tile = item.tile;
         const int cls = item.cls;
+        __syncthreads();  // every wave is done reading LDS for the previous work item
         int n_ops, first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row, save_cls, no_root, alt_codes;
         {
             const ProgHdr &h = item.h;
@@ -1286,18 +1335,18 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         // (-2: no header, the matrices are read from the ops)
         const int first_gemm_mat = item.h.first_gemm_mat, first_leaf_mat = item.h.first_leaf_mat;
         const int second_leaf_mat = item.h.second_leaf_mat, fourth_leaf_row = item.h.fourth_leaf_row;
-        const long long pat0 = (tile * 4 + wave) * (16 * NT) + c;  // this lane's pattern in group 0
+        const unsigned pat0 = (unsigned)((tile * 4 + wave) * (16 * NT)) + (unsigned)c;  // this lane's pattern in group 0
 
         Walk<NT> w{a};
         w.ops = a.ops + (size_t)cls * a.n_ops_pad;
         w.ip = 0;
         w.buf = 0;
-        w.codes = (alt_codes ? a.codes_alt : a.codes) + pat0;
-        w.idx = a.idx32 ? a.idx32 + pat0 : nullptr;
+        w.codes = alt_codes ? a.codes_alt : a.codes;
+        w.pat = pat0;
         w.table_off = ((size_t)tile * 4 + wave) * 8192;
         w.gather0 = (const char *)(a.P + P_IMAGE);
         w.stack = (char *)a.stack + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * slot_bytes;
-        w.stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64) + lane;
+        w.stack_e = a.stack_e + ((size_t)blockIdx.x * 4 + wave) * a.max_depth * (NT * 64);
         w.stack_voff = (unsigned)(lane & 15) * 512u + (unsigned)(lane >> 4) * 16u;
         w.lds_a = (unsigned)(size_t)LDS_PTR(smem) + (g * 4 + (lane & 3)) * 16;
         w.smem = smem;
@@ -1306,6 +1355,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.n_ops = n_ops;
         w.save_stride = (size_t)a.save_K * (size_t)n_tiles * 4 * SAVE_TILE_BYTES;
         w.save0 = a.save ? a.save + (((size_t)save_cls * (size_t)n_tiles + (size_t)tile) * 4 + wave) * SAVE_TILE_BYTES : nullptr;
+        w.more = item_tiles > 1;
 
 #ifdef CRAB_PROF
         w.prof_acc = prof_acc;
@@ -1322,43 +1372,81 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #endif
         }
 
-#ifndef CRAB_ABLATE_ITEM_SYNC
-        __syncthreads();  // every wave is done reading LDS for the previous work item
-#endif
         __builtin_amdgcn_s_setprio(CRAB_PRIO_OTHER);
 #ifndef CRAB_ABLATE_DMA
         if (first_gemm_op >= 0)
 #else
         if (false)
 #endif
-            dma_matrix(a.P + (size_t)(first_gemm_mat >= 0 ? first_gemm_mat : w.ops[first_gemm_op].mat) * P_ELEMS, smem, wave, lane);
+            dma_matrix(a.P + (size_t)(first_gemm_mat >= 0 ? first_gemm_mat : CONST_PTR(DevOp, w.ops)[first_gemm_op].mat) * P_ELEMS, smem, wave, lane);
         // the program is read 64 ops at a time, one op per lane: no scalar-cache miss sits on the walk's critical path
         w.batch = w.ops[lane];
         if (first_leaf_row >= 0) load_code_offsets<NT>(w, first_leaf_row, w.code_off);
         if constexpr (Plan<NT>::HAS_PRE) {
             if (second_leaf_row >= 0) load_code_offsets<NT>(w, second_leaf_row, w.code_off2);
             if (first_leaf_op >= 0) {
-                issue_columns<NT, Plan<NT>::G>(w, first_leaf_mat >= 0 ? first_leaf_mat : w.ops[first_leaf_op].mat);
+                issue_columns<NT, Plan<NT>::G>(w, first_leaf_mat >= 0 ? first_leaf_mat : CONST_PTR(DevOp, w.ops)[first_leaf_op].mat);
                 refill_codes1<NT>(w, third_leaf_row);
                 if (second_leaf_mat != -1) {   // op 1 is the same node's second leaf edge: into the landing tile, in the same round trip
-                    issue_columns<NT, X1>(w, second_leaf_mat >= 0 ? second_leaf_mat : w.ops[1].mat);
+                    issue_columns<NT, X1>(w, second_leaf_mat >= 0 ? second_leaf_mat : CONST_PTR(DevOp, w.ops)[1].mat);
                     refill_codes1<NT>(w, fourth_leaf_row);
                 }
             }
         }
 
-        const size_t out0 = (size_t)cls * a.n_pat_pad + pat0;
+        const size_t out_row = (size_t)cls * a.n_pat_pad;
         PROF_T(0)
-        for (;;) {
+        // The two tiles swap roles at every product.  A later tile of the item starts in the orientation its predecessor ended
+        // in: the last product left the second leaf edge's columns in the tile that is the landing tile from there on.
+        // (Two nested loops, one per orientation, and forward jumps out of them: a flag was taken for divergent by the compiler,
+        // which then ran both orientations under execution masks; jumps INTO a loop make the control flow irreducible, which
+        // the divergence analysis answers by calling everything divergent.)
+        int tt = 0;
+        // The item's next tile (only programs with F_NEXT_TILE come in items of several tiles: the host's promise).  The last
+        // product of the program has requested the columns of this tile's first leaf edges and staged the first product's
+        // operand image into the buffer the walk turns to next; what is left of a prologue is the code queue behind those.
+        auto next_tile = [&]() -> bool {
+            // (readfirstlane: the compiler otherwise takes the tile counter, and through it every request of a cyclic program's
+            // last product, for divergent)
+            tt = __builtin_amdgcn_readfirstlane(tt + 1);
+            if (tt >= item_tiles) return false;
+            PROF_T(10)
+            w.pat += 64 * NT;
+            w.table_off += 4 * 8192;
+            if (w.save0) w.save0 += 4 * SAVE_TILE_BYTES;
+            w.ip = 0;
+            w.more = __builtin_amdgcn_readfirstlane(tt + 1 < item_tiles) != 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) e0[nt] = e1[nt] = 0;
+            if (w.n_ops > 64) w.batch = w.ops[lane];
+            const ProgHdr h2 = load_hdr(a.items + wi);
+            if (h2.second_leaf_mat != -1)
+                refill_codes2<NT>(w, h2.third_leaf_row, h2.fourth_leaf_row);
+            else
+                refill_codes2<NT>(w, h2.second_leaf_row, h2.third_leaf_row);
+            return true;
+        };
+        for (;;) {   // orientation 0: tile 0 is the current tile
             if (walk<NT, X0, X1>(w, e0, e1)) {
-                if (!no_root) root_sum<NT, X0>(a, e0, out0, g);
-                break;
+                // (a program that ends in a site likelihood is the last tile of its item whatever the item says: the walk's
+                // state is then dead across the root sum, which needs the registers)
+                if (!no_root) {
+                    root_sum<NT, X0>(a, e0, out_row, w.pat, g);
+                    goto item_done;
+                }
+                if (!next_tile()) goto item_done;
+                continue;
             }
-            if (walk<NT, X1, X0>(w, e1, e0)) {
-                if (!no_root) root_sum<NT, X1>(a, e1, out0, g);
-                break;
+            for (;;) {   // orientation 1, until the next product
+                if (!walk<NT, X1, X0>(w, e1, e0)) break;
+                if (!no_root) {
+                    root_sum<NT, X1>(a, e1, out_row, w.pat, g);
+                    goto item_done;
+                }
+                if (!next_tile()) goto item_done;
             }
         }
+    item_done:;
 #ifdef CRAB_PROF
         PROF_T(0)
         prof_acc = w.prof_acc;
@@ -1379,17 +1467,23 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 }
 
 // amdgpu_num_vgpr wants a literal: one entry point per tile width
+// amdgpu_num_vgpr alone confines nothing (measured in round 3: the same code comes out with 40, 48, 64 or no attribute at all,
+// and under more pressure the allocator simply goes higher -- rounds 1-2 stayed below 64 by the size of the code alone).
+// amdgpu_waves_per_eu does: asking for 8 waves per SIMD caps the allocator at 512 / 8 = 64 registers, and it spills to
+// scratch beyond that ("failed to meet occupancy target" is the expected remark: the fixed tiles above make it 2).
 #ifdef CRAB_PROF
 #define CRAB_CC_NT1 96
+#define CRAB_WAVES_NT1 5
 #else
 #define CRAB_CC_NT1 64
+#define CRAB_WAVES_NT1 8
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(CRAB_CC_NT1))) void prune_kernel_nt1(PruneArgs a, long long n_tiles)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(CRAB_CC_NT1), amdgpu_waves_per_eu(CRAB_WAVES_NT1, CRAB_WAVES_NT1))) void prune_kernel_nt1(PruneArgs a, long long n_tiles)
 {
     static_assert(Plan<1>::CC == CRAB_CC_NT1, "");
     prune_body<1>(a, n_tiles);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96))) void prune_kernel_nt2(PruneArgs a, long long n_tiles)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96), amdgpu_waves_per_eu(5, 5))) void prune_kernel_nt2(PruneArgs a, long long n_tiles)
 {
     static_assert(Plan<2>::CC == 96, "");
     prune_body<2>(a, n_tiles);
@@ -1407,7 +1501,7 @@ static int chosen_nt()
     }
     return g_nt;
 }
-static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double); }
+static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double); }   // two operand images
 static int g_blocks_per_cu = 0;
 static int blocks_per_cu()
 {
@@ -1508,7 +1602,7 @@ void launch_prune(const PruneArgs &args, int grid, hipStream_t stream)
     if (d_prof) {
         (void)hipStreamSynchronize(stream);
         static const char *names[12] = {"prologue+root", "gemm wait vmcnt", "gemm barrier", "gemm dma issue + mfma", "gemm pop-mul",
-                                        "leaf gather issue + wait", "leaf multiply", "normalise", "push", "late column issue + loop", "-", "op decode"};
+                                        "leaf gather issue + wait", "leaf multiply", "normalise", "push", "late column issue + loop", "next tile of the item", "op decode"};
         std::vector<unsigned long long> h((size_t)grid * 4 * 12);
         (void)hipMemcpy(h.data(), d_prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double tot[12] = {0}, all = 0;
