@@ -2016,6 +2016,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                         int32_t prog, tile0, n;
                         double w;
                     };
+                    auto env_w = [](const char *name, double dflt) {
+                        const char *sv = std::getenv(name);
+                        return sv && sv[0] ? std::atof(sv) : dflt;
+                    };
+                    const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
+                    // the second workgroup of a CU runs ~8 % slower than the first (the issue arbiter serves the older one first)
+                    const double slow_slot = env_w("CRAB_W_SLOT", 1.08);
                     std::vector<Item> its;
                     for (int t = 0; t < n_tab; ++t)
                         for (int j : order) {
@@ -2025,8 +2032,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                             const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
                             for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
                                 const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
+                                // predicted time in products: a prologue, and per tile its products and a sixth of a product for the
+                                // rest (fitted to per-workgroup busy times, scripts/gpu_prof_phases.sh with -DCRAB_CLOCK)
                                 its.push_back({(int32_t)(pl.K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo),
-                                               1.0 + (double)(hi - lo) * (in.n_gemm + 0.1 * (in.n_ops - in.n_gemm))});
+                                               w_item + (double)(hi - lo) * (in.n_gemm + w_tile)});
                             }
                             e->dev_gemm_extra += (int64_t)in.n_gemm * tiles * prune_tile_width();
                         }
@@ -2054,7 +2063,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                         std::vector<double> load(per_xcd, 0.0);
                         for (int i : by_w) {
                             const int j = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-                            load[j] += its[i].w;
+                            load[j] += its[i].w * (2 * j >= per_xcd ? slow_slot : 1.0);   // (workgroups per_xcd/2.. are second on their CUs)
                             of_wg[j * 8 + c8].push_back(i);
                         }
                     }
