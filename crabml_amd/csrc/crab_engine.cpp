@@ -478,8 +478,7 @@ struct crab_engine : TreeProgram {
     struct CladeLaunch {                // one launch of clade programs (one level)
         int list_off = 0, n_entries = 0;      // its entries of the program list
         int64_t items_off = 0, n_items = 0;   // its work items
-        int grid = 0;                          // its workgroups ...
-        int64_t wg_off = 0;                    // ... and where their item ranges start in d_wg_begin (grid + 1 entries)
+        int grid = 0;                          // its workgroups
         int64_t bounds[9] = {0};
     };
     std::vector<CladeLaunch> dev_clade_launches;
@@ -503,7 +502,7 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_wg_begin;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_work_ctr;
     DevBuf<ProgHdr> d_items;
     DevBuf<uint32_t> d_idx32;
     DevBuf<uint8_t> d_codes_alt;
@@ -542,7 +541,7 @@ struct crab_engine : TreeProgram {
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_wg_begin.release(); d_idx32.release(); d_codes_alt.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_work_ctr.release(); d_idx32.release(); d_codes_alt.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
         h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release(); d_eig_status.release(); h_eig_status.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -1936,7 +1935,6 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             int32_t prog, tile0, n;
         };
         std::vector<ItemRef> items;                 // clade launches: (program, first tile, tiles) per work item
-        std::vector<int32_t> wg_begin;              // ... and per launch, which items each workgroup walks (grid + 1 entries)
         if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
@@ -2021,8 +2019,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                         return sv && sv[0] ? std::atof(sv) : dflt;
                     };
                     const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
-                    // the second workgroup of a CU runs ~8 % slower than the first (the issue arbiter serves the older one first)
-                    const double slow_slot = env_w("CRAB_W_SLOT", 1.08);
+
                     std::vector<Item> its;
                     for (int t = 0; t < n_tab; ++t)
                         for (int j : order) {
@@ -2042,8 +2039,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                     cl.n_entries = (int)lists.size() - cl.list_off;
                     cl.n_items = (int64_t)its.size();
                     // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that share
-                    // an L2 walk the same matrices).  Inside a chunk the items are assigned to the XCD's workgroups longest first,
-                    // each to the workgroup with the least work so far; a workgroup walks its items in the original order.
+                    // an L2 walk the same matrices); inside a chunk the longest items first -- the kernel hands a chunk's items out in
+                    // order to whichever of the XCD's workgroups asks next, so the tail of the launch is a short item.
                     double total = 0.0, acc = 0.0;
                     for (const Item &it : its) total += it.w;
                     int x = 1;
@@ -2054,27 +2051,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                     }
                     while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
                     cl.grid = prune_grid_size((int64_t)its.size(), e->device);
-                    const int per_xcd = cl.grid / 8;
-                    std::vector<std::vector<int>> of_wg(cl.grid);
-                    for (int c8 = 0; c8 < 8 && per_xcd > 0; ++c8) {
-                        std::vector<int> by_w;
-                        for (int64_t i = cl.bounds[c8]; i < cl.bounds[c8 + 1]; ++i) by_w.push_back((int)i);
-                        std::stable_sort(by_w.begin(), by_w.end(), [&](int p, int q) { return its[p].w > its[q].w; });
-                        std::vector<double> load(per_xcd, 0.0);
-                        for (int i : by_w) {
-                            const int j = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-                            load[j] += its[i].w * (2 * j >= per_xcd ? slow_slot : 1.0);   // (workgroups per_xcd/2.. are second on their CUs)
-                            of_wg[j * 8 + c8].push_back(i);
-                        }
-                    }
-                    cl.wg_off = (int64_t)wg_begin.size();
-                    int32_t n_out = 0;
-                    for (int b = 0; b < cl.grid; ++b) {
-                        wg_begin.push_back(n_out);
-                        std::sort(of_wg[b].begin(), of_wg[b].end());
-                        for (int i : of_wg[b]) items.push_back({its[i].prog, its[i].tile0, its[i].n}), ++n_out;
-                    }
-                    wg_begin.push_back(n_out);
+                    for (int c8 = 0; c8 < 8; ++c8)
+                        std::stable_sort(its.begin() + cl.bounds[c8], its.begin() + cl.bounds[c8 + 1],
+                                         [](const Item &p, const Item &q) { return p.w > q.w; });
+                    for (const Item &it : its) items.push_back({it.prog, it.tile0, it.n});
                 }
             }
             first_off = (int)lists.size();
@@ -2155,9 +2135,6 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             item_recs[i] = hdrs[items[i].prog];
             item_recs[i].prog = items[i].prog, item_recs[i].tile0 = items[i].tile0, item_recs[i].item_tiles = items[i].n;
         }
-        e->d_wg_begin.ensure(wg_begin.size() + 1);
-        if (!wg_begin.empty())
-            HIP_CHECK(hipMemcpyAsync(e->d_wg_begin.p, wg_begin.data(), wg_begin.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         e->d_items.ensure(item_recs.size() + 1);
         if (!item_recs.empty())
             HIP_CHECK(hipMemcpyAsync(e->d_items.p, item_recs.data(), item_recs.size() * sizeof(ProgHdr), hipMemcpyHostToDevice, e->stream));
@@ -2256,6 +2233,19 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.third_leaf_row = e->third_leaf_row;
     pa.second_leaf_op = e->second_leaf_op;
     pa.fourth_leaf_row = e->fourth_leaf_row;
+    // Every launch of the pruning kernel hands its items out through eight counters of its own (PruneArgs::work_ctr;
+    // CRAB_STATIC_ITEMS=1: items dealt round-robin instead, as in rounds 1-2).
+    constexpr int MAX_PRUNE_LAUNCHES = 16;
+    static const bool dynamic_items = [] {
+        const char *sv = std::getenv("CRAB_STATIC_ITEMS");
+        return !(sv && sv[0] && sv[0] != '0');
+    }();
+    if (dynamic_items) {
+        e->d_work_ctr.ensure(8 * MAX_PRUNE_LAUNCHES);
+        if ((int)e->dev_clade_launches.size() + 2 > MAX_PRUNE_LAUNCHES) fail(CRAB_ERR_ARG, "too many clade levels");
+        HIP_CHECK(hipMemsetAsync(e->d_work_ctr.p, 0, 8 * MAX_PRUNE_LAUNCHES * sizeof(int32_t), e->stream));
+    }
+    int launch_no = 0;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     if (use_clades) {     // one launch per level: the clade programs, over each clade's distinct sub-patterns
         PruneArgs pc = pa;
@@ -2270,19 +2260,21 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             pc.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
             pc.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
             std::copy(cl.bounds, cl.bounds + 9, pc.xcd_bounds);
-            pc.wg_begin = e->d_wg_begin.p + cl.wg_off;
+            pc.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
             launch_prune(pc, cl.grid, e->stream);
         }
         // the main programs (among the first launch's) read the outermost clades' tables through the last block of wide rows
         pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
         pa.n_code_rows = e->aln_rows;
     }
+    pa.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
     launch_prune(pa, grid, e->stream);
     if (two_launches) {   // path programs / root programs read what the first launch saved: same stream, after it
         pa.K = n_second;
         pa.cls_list = e->d_cls.p + e->dev_first_off + n_first;
         std::copy(e->dev_bounds_second, e->dev_bounds_second + 9, pa.xcd_bounds);
-            launch_prune(pa, grid_second, e->stream);
+            pa.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
+        launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
 
@@ -2628,6 +2620,7 @@ int crab_create(int device, crab_engine **out)
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             throw HipError{std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only"};
+        HIP_CHECK((hipError_t)prune_configure_device());
         HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&e->ev_begin));
         HIP_CHECK(hipEventCreate(&e->ev_end));

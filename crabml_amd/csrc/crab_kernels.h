@@ -184,7 +184,8 @@ struct PruneArgs {
     const uint8_t *codes_alt; // [n_rows][n_pat_pad] like codes
     const uint32_t *idx32;    // [n_clades][n_pat_pad]
     int32_t n_code_rows;      // rows of `codes`; 0 = no wide rows in this launch
-    const int32_t *wg_begin;  // with items: workgroup b walks items [wg_begin[b], wg_begin[b + 1]) (grid + 1 entries), or nullptr
+    int32_t *work_ctr;        // [8], zero before the launch: XCD x's workgroups take the items of its chunk in order, one at a
+                              // time, whoever asks next (see prune_body); nullptr: a chunk's items are dealt round-robin
 #ifdef CRAB_PROF
     unsigned long long *prof; // diagnostic builds: per-wave phase counters (set by launch_prune), or nullptr
 #endif
@@ -202,6 +203,9 @@ int prune_grid_size(int64_t n_work, int device);
 // Bytes of stack / stack_e needed for a grid of `grid` workgroups and `max_depth` slots.
 size_t prune_stack_doubles(int grid, int max_depth);
 size_t prune_stack_ints(int grid, int max_depth);
+// Once per device, with that device current, before the first launch_prune on it: the pruning kernels use a little more than
+// the 64 KiB of LDS a kernel gets without asking (two operand images + the work-item mailbox).  Returns a HIP error code.
+int prune_configure_device();
 void launch_prune(const PruneArgs &a, int grid, hipStream_t stream);
 
 // ---- kernel 3: class mixture, log, weighted sum  ---------------------------------------------

@@ -550,6 +550,11 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
+// The hazard recognizer does not look inside inline asm: a vector-memory instruction that reads a scalar register written by a
+// VALU instruction (v_readlane, v_readfirstlane: how a spilled or "proven" wave-uniform base gets back into scalar registers)
+// needs five wait states in between, which the compiler inserts for its own instructions only.  One s_nop 4 in front of every
+// asm sequence that takes a scalar base.  (A build whose bases all came through v_readfirstlane faulted on the GPU.)
+__device__ __forceinline__ void r_sgpr_hazard() { asm volatile("s_nop 4" ::: "memory"); }
 __device__ __forceinline__ void r_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- tile-wide operations ----
@@ -617,6 +622,7 @@ template <int NT, int D>
 __device__ __forceinline__ void t_load(const void *sbase, unsigned voff)
 {
     using S8 = std::make_integer_sequence<int, 8>;
+    r_sgpr_hazard();
     t_gather_seq<D>(sbase, voff, S8{});
     if constexpr (NT == 2) t_gather_seq<D + 32>(sbase, voff + 8192, S8{});
 }
@@ -624,6 +630,7 @@ template <int NT, int S>
 __device__ __forceinline__ void t_store(void *sbase, unsigned voff)
 {
     using S8 = std::make_integer_sequence<int, 8>;
+    r_sgpr_hazard();
     t_scatter_seq<S>(sbase, voff, S8{});
     if constexpr (NT == 2) t_scatter_seq<S + 32>(sbase, voff + 8192, S8{});
 }
@@ -937,6 +944,7 @@ __device__ __forceinline__ void issue_columns(Walk<NT> &w, int mat)
     // (readfirstlane: the "s" operand of the loads must be provably wave-uniform)
     const char *img = uniform_ptr(w.gather0 + (size_t)__builtin_amdgcn_readfirstlane(mat) * (P_ELEMS * 8));
     using S8 = std::make_integer_sequence<int, 8>;
+    r_sgpr_hazard();
 #ifdef CRAB_ABLATE_GATHER
     (void)img;
 #else
@@ -1293,11 +1301,43 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
     const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
-    // A launch with an item list says which items each workgroup walks (wg_begin: the host balances the predicted work of
-    // the workgroups of an XCD over that XCD's chunk); otherwise a chunk's items are dealt round-robin to its workgroups.
-    long long wi_first = chunk_lo + xj, wi_end = chunk_hi, wi_step = per_xcd;
-    if (a.items && a.wg_begin) wi_first = a.wg_begin[blockIdx.x], wi_end = a.wg_begin[blockIdx.x + 1], wi_step = 1;
-    for (long long wi = wi_first; wi < wi_end; wi += wi_step) {
+    // Work distribution.  With work_ctr: the items of an XCD's chunk are handed out in order, one at a time, to whichever of
+    // that XCD's workgroups asks next (the host puts the long items first: the tail of a launch is one short item).  Thread 0
+    // takes the next number with a returning atomic at the end of the current item's prologue -- it comes back with the
+    // prologue's own loads -- and posts it in an LDS mailbox (two slots used in turn, behind the operand images) that the whole
+    // workgroup reads after the barrier that opens the next item.  Which workgroup walks an item matters to no result.  The
+    // atomic and the mailbox are inline asm on purpose: with a C++ atomic and a volatile LDS array in the loop the compiler
+    // took the whole walk for divergent, ran it under execution masks and spilled forty registers (and that build faulted).
+    // Without work_ctr: a chunk's items are dealt round-robin to its workgroups.
+    const bool dynamic = a.work_ctr != nullptr;
+    const unsigned mbox = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)(2 * P_IMAGE * sizeof(double));
+    int *const ctr = uniform_ptr(a.work_ctr + xcd);
+    auto post_next_number = [&](unsigned slot_addr) {
+        if (threadIdx.x == 0) {
+            int number;
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %4, %0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(number)
+                         : "v"(0), "v"(1), "s"(ctr), "v"(slot_addr)
+                         : "memory");
+        }
+    };
+    auto read_number = [&](unsigned slot_addr) {
+        int number;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(number) : "v"(slot_addr) : "memory");
+        return __builtin_amdgcn_readfirstlane(number);
+    };
+    if (dynamic) post_next_number(mbox);
+    long long taken = 0;   // (an exit every wave reaches whatever the mailbox holds: never more items than the chunk has)
+    long long wi = chunk_lo + xj - per_xcd;
+    for (int par = 0;; par ^= 1) {
+        __syncthreads();  // the mailbox is written; every wave is done reading LDS for the previous work item
+        if (dynamic) {
+            wi = chunk_lo + read_number(mbox + 4 * par);
+            if (wi < chunk_lo || ++taken > chunk_hi - chunk_lo) break;
+        } else {
+            wi += per_xcd;
+        }
+        if (wi >= chunk_hi) break;
         struct {
             int cls;
             long long tile;
@@ -1323,7 +1363,6 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         }
         const long long tile = item.tile;
         const int cls = item.cls;
-        __syncthreads();  // every wave is done reading LDS for the previous work item
         int n_ops, first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row, save_cls, no_root, alt_codes;
         {
             const ProgHdr &h = item.h;
@@ -1394,6 +1433,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             }
         }
 
+        if (dynamic) post_next_number(mbox + 4 * (par ^ 1));
         const size_t out_row = (size_t)cls * a.n_pat_pad;
         PROF_T(0)
         // The two tiles swap roles at every product.  A later tile of the item starts in the orientation its predecessor ended
@@ -1501,7 +1541,7 @@ static int chosen_nt()
     }
     return g_nt;
 }
-static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double); }   // two operand images
+static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double) + 64; }   // two operand images + the item mailbox
 static int g_blocks_per_cu = 0;
 static int blocks_per_cu()
 {
@@ -1520,6 +1560,13 @@ static int blocks_per_cu()
     return g_blocks_per_cu;
 }
 
+int prune_configure_device()
+{
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(prune_kernel_nt1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds_bytes());
+    if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(prune_kernel_nt2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds_bytes());
+    return (int)err;
+}
 int prune_tile_width() { return 64 * chosen_nt(); }
 int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }
 bool prune_has_prefetch() { return chosen_nt() == 1 ? Plan<1>::HAS_PRE : Plan<2>::HAS_PRE; }
