@@ -1529,35 +1529,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(96), amdgpu_wav
     prune_body<2>(a, n_tiles);
 }
 
-static int g_nt = 0;
+// (function-local statics: initialised once, thread-safely, whichever thread asks first -- the shard workers of a
+// multi-device handle ask concurrently)
 static int chosen_nt()
 {
-    if (g_nt == 0) {
-        g_nt = 1;
+    static const int nt = [] {
         if (const char *s = std::getenv("CRAB_NT")) {
             const int v = std::atoi(s);
-            if (v == 1 || v == 2) g_nt = v;
+            if (v == 1 || v == 2) return v;
         }
-    }
-    return g_nt;
+        return 1;
+    }();
+    return nt;
 }
 static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double) + 64; }   // two operand images + the item mailbox
-static int g_blocks_per_cu = 0;
+// Resident workgroups per CU (every gfx950 device gives the same answer: the kernel's registers and LDS decide).  First asked
+// by prune_configure_device, on the thread that creates the engine and with its device current.
 static int blocks_per_cu()
 {
-    if (g_blocks_per_cu == 0) {
+    static const int bpc = [] {
         int occ = 0;
         const hipError_t err = chosen_nt() == 1
                                    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel_nt1, 256, prune_lds_bytes())
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, prune_kernel_nt2, 256, prune_lds_bytes());
         const int want = 2;
-        g_blocks_per_cu = (err == hipSuccess && occ >= 1) ? (occ > want ? want : occ) : 1;
+        int v = (err == hipSuccess && occ >= 1) ? (occ > want ? want : occ) : 1;
         if (const char *s = std::getenv("CRAB_BLOCKS_PER_CU")) {
-            const int v = std::atoi(s);
-            if (v >= 1 && v <= g_blocks_per_cu) g_blocks_per_cu = v;
+            const int w = std::atoi(s);
+            if (w >= 1 && w <= v) v = w;
         }
-    }
-    return g_blocks_per_cu;
+        return v;
+    }();
+    return bpc;
 }
 
 int prune_configure_device()
@@ -1565,6 +1568,7 @@ int prune_configure_device()
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(prune_kernel_nt1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds_bytes());
     if (err == hipSuccess)
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(prune_kernel_nt2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds_bytes());
+    if (err == hipSuccess) (void)blocks_per_cu();
     return (int)err;
 }
 int prune_tile_width() { return 64 * chosen_nt(); }

@@ -1,5 +1,6 @@
 // crab_matrix_exponential_noalloc: crab_matrix_exponential for callers that must not allocate device memory
-// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+// (tight serving loops, harnesses that forbid hipMalloc).  Not for use WHILE a stream capture is active: the copies are
+// synchronous and the launch goes to the null stream.  The caller's current device is restored on return.
 //
 // crab_matrix_exponential stages the packed eigensystem, the time, the eigensystem index and the 64 KiB output
 // images of build_p_kernel in device buffers that it allocates and frees per call.  Here the same kernel runs on a
@@ -92,6 +93,12 @@ extern "C" int crab_matrix_exponential_noalloc(int device, int n, const double *
     if (!crab::spectral_decompose(n, Q, pi, eig.data())) return fail(CRAB_ERR_EIGEN, "Eigendecomposition failed");
 
     std::lock_guard<std::mutex> lk(g_dev[device].m);
+    int caller_device = -1;
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
+    struct RestoreDevice {
+        int d;
+        ~RestoreDevice() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{caller_device == device ? -1 : caller_device};
     hipError_t err = hipSetDevice(device);
     double *scr = nullptr;
     if (err == hipSuccess) err = scratch_address(device, &scr);

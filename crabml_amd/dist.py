@@ -30,7 +30,9 @@ def pattern_slices(n_patterns: int, world_size: int, align: int = 128):
     return out
 
 
-_GATHER_BUFFERS = {}   # (group id, device, n) -> buffers of all_gather_doubles, made once: the step loop allocates nothing
+_GATHER_BUFFERS = {}   # (thread, group id, world size, device, n) -> buffers of all_gather_doubles, made once: the step loop
+                       # allocates nothing.  Per thread (concurrent callers, e.g. map_genes workers, must not share a send
+                       # buffer); the world size is part of the key because id() of a destroyed group can be reused.
 
 
 def all_gather_doubles(vec, group=None, device=None) -> "np.ndarray":
@@ -47,8 +49,11 @@ def all_gather_doubles(vec, group=None, device=None) -> "np.ndarray":
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     device = torch.device(device)
     n = vec.size
-    key = (id(group) if group is not None else 0, str(device), n)
+    import threading
+    key = (threading.get_ident(), id(group) if group is not None else 0, ws, str(device), n)
     buf = _GATHER_BUFFERS.get(key)
+    if buf is not None and buf[3].numel() != ws * n:   # (belt and braces: never reshape a stale receive buffer)
+        buf = None
     if buf is None:
         on_gpu = device.type == "cuda"
         host_send = torch.empty(n, dtype=torch.float64, pin_memory=on_gpu)

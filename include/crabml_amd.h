@@ -251,8 +251,9 @@ int crab_export_transition_matrices(crab_engine *e, int k, double *P_out);
 /* matrix_exponential (lib.rs:61-79 -> matrix.rs:31-102): P = exp(Q t), computed on the device
  * with the same batched kernel the evaluations use.  P_out: [n][n]. */
 int crab_matrix_exponential(int device, int n, const double *Q, const double *pi, double t, double *P_out);
-/* crab_matrix_exponential for callers that cannot allocate device memory: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose expm allocates a fresh ndarray
+/* crab_matrix_exponential for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs between the capture sections of a HIP graph (the call itself copies synchronously and launches
+ * on the null stream, so it must not be made WHILE a stream capture is active; it restores the caller's current device).  It has no counterpart in the reference (whose expm allocates a fresh ndarray
  * per call, matrix.rs:88-102).  Same arguments and results as crab_matrix_exponential (bit-identical: same host
  * decomposition, same kernel); the eigensystem, time and output images that crab_matrix_exponential stages in
  * device buffers allocated per call live in a file-scope device array instead -- 131 616 bytes per GPU, held from the

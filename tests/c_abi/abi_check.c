@@ -38,9 +38,16 @@ int main(void)
         if (crab_create(0, &e) != CRAB_OK) return 10;
         if (crab_set_tree(e, 5, NULL, parents, leaves, 3) != CRAB_OK) return 11;
         if (crab_set_alignment(e, codes, 3, 2, 61, 1, 0, -1) != CRAB_OK) return 12;
-        if (crab_eval_site_classes(e, 1, Q, &one, pi, bl, 0, &lnL, NULL) != CRAB_OK || !(lnL < 0.0)) return 13;
+        /* the oracle's value for this 3-leaf case (oracle.compute_site_class_log_likelihood on the same Q, pi, tree, branch
+         * lengths and codes; tests/test_c_abi.py recomputes it and compares with this constant): total lnL within 1e-10 relative */
+        const double lnL_oracle = -11.394229542297818;
+        if (crab_eval_site_classes(e, 1, Q, &one, pi, bl, 0, &lnL, NULL) != CRAB_OK) return 13;
+        if (!(fabs(lnL - lnL_oracle) <= 1e-10 * fabs(lnL_oracle))) {
+            printf("abi: device lnL %.15f differs from the oracle's %.15f\n", lnL, lnL_oracle);
+            return 14;
+        }
         crab_destroy(e);
-        printf("abi ok (device: lnL %.6f)\n", lnL);
+        printf("abi ok (device: lnL %.12f)\n", lnL);
     }
     return 0;
 }

@@ -46,6 +46,27 @@ def test_noalloc_matrix_exponential_equals_the_allocating_entry_point(gpu_engine
         np.testing.assert_allclose(got.sum(axis=1), 1.0, rtol=0, atol=1e-12)
 
 
+def test_noalloc_entry_point_allocates_no_device_memory(gpu_engine_cls):
+    """After the first call on the device (which makes the runtime load the code object that holds the array), further calls
+    leave the device's free memory where it was -- read with hipMemGetInfo through the HIP runtime the library itself uses."""
+    lib = L.load()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    Q, pi = _reversible_q(61, 7)
+    _expm(lib.crab_matrix_exponential_noalloc, Q, pi, 0.2)   # first call: symbol lookup, code object
+    before = free_bytes()
+    for n, seed in ((61, 8), (33, 9), (61, 10), (7, 11)):
+        Qn, pin = _reversible_q(n, seed)
+        _expm(lib.crab_matrix_exponential_noalloc, Qn, pin, 0.3)
+        assert free_bytes() == before
+
+
 def test_noalloc_rejects_sizes_beyond_its_array(gpu_engine_cls):
     lib = L.load()
     Q, pi = _reversible_q(61, 5)
