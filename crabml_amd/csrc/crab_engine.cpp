@@ -3471,6 +3471,18 @@ int crab_discretise_omega(int kind, double a, double b, int K, double *omegas_ou
     });
 }
 
+int crab_discretise_omega_mixture(int kind, const double *params, int n_params, int K, double *omegas_out)
+{
+    return guarded(nullptr, [&] {
+        if (K < 1 || !omegas_out || !params || (kind != 2 && kind != 3) || n_params != (kind == 2 ? 4 : 5))
+            fail(CRAB_ERR_ARG, "crab_discretise_omega_mixture: kind 2 (M6) takes 4 parameters, kind 3 (M9) takes 5");
+        for (int i = 0; i < n_params; ++i)
+            if (!std::isfinite(params[i])) fail(CRAB_ERR_ARG, "crab_discretise_omega_mixture: parameters must be finite");
+        if (!mixture_median_quantiles(kind, params, K, omegas_out))
+            fail(CRAB_ERR_ARG, "crab_discretise_omega_mixture: Brent's iteration did not converge in 100 steps");
+    });
+}
+
 int crab_build_site_class_q_matrices(int K, double kappa, const double *omegas, const double *proportions, const double *pi,
                                      double *Q_out)
 {

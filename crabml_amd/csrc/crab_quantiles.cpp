@@ -158,4 +158,122 @@ double gamma_ppf(double p, double a, double scale)
     return std::exp(u) * scale;
 }
 
+
+// ---- M6 / M9: quantiles of a mixture CDF ------------------------------------------------------------------------------------
+namespace {
+
+// scipy.stats.beta.cdf(x, a, b) / scipy.stats.gamma.cdf(x, a, scale = 1 / rate) on the bracket the reference searches
+double beta_cdf_value(double x, double a, double b, double lbeta)
+{
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    double F, Fc;
+    beta_cdf(a, b, x, 1.0 - x, std::log(x), std::log1p(-x), lbeta, &F, &Fc);
+    return F;
+}
+double gamma_cdf_value(double x, double a, double rate, double lgam)
+{
+    const double scale = 1.0 / rate, y = x / scale;   // (scipy's loc-scale wrapper: (x - loc) / scale with the reference's scale = 1.0 / rate)
+    if (y <= 0.0) return 0.0;
+    double F, Fc;
+    gamma_cdf(a, y, std::log(y), lgam, &F, &Fc);
+    return F;
+}
+
+// Brent's method in the form of scipy.optimize.brentq (scipy 1.15, scipy/optimize/Zeros/brentq.c; a dependency of the
+// reference, not part of it: restated from the published algorithm, same variables, same order of the tests, so that the
+// iterates -- and with them the last digits the reference's omegas carry at xtol = 2e-12 -- are the reference's).
+// status: 0 converged, 1 no sign change over [xa, xb], 2 not converged in `iter` steps.
+template <typename F>
+double brentq_like_scipy(F &&f, double xa, double xb, double xtol, double rtol, int iter, int *status)
+{
+    double xpre = xa, xcur = xb, xblk = 0.0, fpre, fcur, fblk = 0.0, spre = 0.0, scur = 0.0, sbis, delta, stry, dpre, dblk;
+    *status = 0;
+    fpre = f(xpre);
+    fcur = f(xcur);
+    if (fpre == 0.0) return xpre;
+    if (fcur == 0.0) return xcur;
+    if (std::signbit(fpre) == std::signbit(fcur)) {
+        *status = 1;
+        return 0.0;
+    }
+    for (int i = 0; i < iter; ++i) {
+        if (fpre != 0.0 && fcur != 0.0 && std::signbit(fpre) != std::signbit(fcur)) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (std::fabs(fblk) < std::fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        delta = (xtol + rtol * std::fabs(xcur)) / 2.0;
+        sbis = (xblk - xcur) / 2.0;
+        if (fcur == 0.0 || std::fabs(sbis) < delta) return xcur;
+        if (std::fabs(spre) > delta && std::fabs(fcur) < std::fabs(fpre)) {
+            if (xpre == xblk) {   // interpolate
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {              // extrapolate
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2.0 * std::fabs(stry) < std::fmin(std::fabs(spre), 3.0 * std::fabs(sbis) - delta)) {   // good short step
+                spre = scur;
+                scur = stry;
+            } else {              // bisect
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {                  // bisect
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (std::fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0.0 ? delta : -delta);
+        fcur = f(xcur);
+    }
+    *status = 2;
+    return xcur;
+}
+
+}  // namespace
+
+bool mixture_median_quantiles(int kind, const double *params, int K, double *out)
+{
+    // the reference's constructor clamps (models/codon.py:1168-1172 M6, :966-971 M9)
+    const double p0 = std::fmin(std::fmax(params[0], 1e-6), 1.0 - 1e-6);
+    double a1 = 0, b1 = 0, a2 = 0, b2 = 0, lg1 = 0, lg2 = 0, lbeta = 0;
+    if (kind == 2) {
+        a1 = std::fmax(params[1], 0.005), b1 = std::fmax(params[2], 0.005), a2 = std::fmax(params[3], 0.005), b2 = a2;
+        lg1 = std::lgamma(a1), lg2 = std::lgamma(a2);
+    } else {
+        a1 = std::fmax(params[1], 0.005), b1 = std::fmax(params[2], 0.005);   // beta(p, q)
+        a2 = std::fmax(params[3], 0.005), b2 = std::fmax(params[4], 0.005);   // gamma(shape, rate)
+        lbeta = std::lgamma(a1) + std::lgamma(b1) - std::lgamma(a1 + b1), lg2 = std::lgamma(a2);
+    }
+    for (int j = 0; j < K; ++j) {
+        const double p = (j * 2.0 + 1.0) / (2.0 * K);
+        // cdf(x) - p with the reference's grouping: p0 * F1 + (1.0 - p0) * F2, then minus p
+        auto g = [&](double x) {
+            const double F1 = kind == 2 ? gamma_cdf_value(x, a1, b1, lg1) : beta_cdf_value(x, a1, b1, lbeta);
+            const double F2 = gamma_cdf_value(x, a2, b2, lg2);
+            return (p0 * F1 + (1.0 - p0) * F2) - p;
+        };
+        int status = 0;
+        const double x = brentq_like_scipy(g, 0.0001, 99.0, 2e-12, 8.881784197001252e-16, 100, &status);
+        if (status == 2) return false;
+        out[j] = status == 1 ? p * 10 : x;
+    }
+    return true;
+}
+
 }  // namespace crab

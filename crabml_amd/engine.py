@@ -495,6 +495,16 @@ def discretise_omega(kind, a, b, K):
     return out
 
 
+def discretise_omega_mixture(kind, params, K):
+    """Median-quantile class omegas of a two-component mixture: kind "M6" (p0, alpha1, beta1, alpha2) or "M9" (p0, p_beta,
+    q_beta, alpha, beta_gamma); Brent's method as scipy.optimize.brentq runs it (crab_discretise_omega_mixture; host only)."""
+    lib = L.load()
+    pr, prp = L.f64(params)
+    out = np.empty(int(K))
+    L.check(lib.crab_discretise_omega_mixture({"M6": 2, "M9": 3}[kind], prp, len(pr), int(K), out.ctypes.data_as(L.dp)))
+    return out
+
+
 def model_a_quantities(kappa, omega0, omega2, p0, p1, pi):
     """(site_class_freqs[4], (qfactor_back, qfactor_fore)) as crab_eval_codon_branch_site computes them (host only)."""
     lib = L.load()

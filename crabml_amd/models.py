@@ -237,7 +237,17 @@ def _mixture_quantiles(cdf, K):
     return out
 
 
+@functools.lru_cache(maxsize=256)
+def _mixture_quantiles_c(kind, params, K):
+    """The same quantiles from the C library (crab_discretise_omega_mixture: Brent's method as scipy.optimize.brentq runs it;
+    equal to the scipy route to ~1e-14 on the fixtures, tests/test_host_logic.py).  Used by the optimiser mirrors."""
+    from .engine import discretise_omega_mixture
+    return tuple(float(x) for x in discretise_omega_mixture(kind, list(params), K))
+
+
 class M6CodonModel(_SiteClassModel):
+    c_quantiles = False    # instances made by the optimiser mirrors set this
+
     def __init__(self, kappa=2.0, p0=0.5, alpha1=1.0, beta1=1.0, alpha2=1.0, ncatG=10, pi=None):
         self.kappa = kappa
         self.p0 = float(np.clip(p0, 1e-6, 1 - 1e-6))
@@ -246,14 +256,18 @@ class M6CodonModel(_SiteClassModel):
         self.pi = _normalise_pi(pi)
 
     def get_site_classes(self):
-        from scipy.stats import gamma
         K = self.ncatG
+        if self.c_quantiles:
+            return [1.0 / K] * K, list(_mixture_quantiles_c("M6", (self.p0, self.alpha1, self.beta1, self.alpha2), K))
+        from scipy.stats import gamma
         cdf = lambda x: (self.p0 * gamma.cdf(x, self.alpha1, scale=1.0 / self.beta1)
                          + (1 - self.p0) * gamma.cdf(x, self.alpha2, scale=1.0 / self.alpha2))
         return [1.0 / K] * K, _mixture_quantiles(cdf, K)
 
 
 class M9CodonModel(_SiteClassModel):
+    c_quantiles = False
+
     def __init__(self, kappa=2.0, p0=0.5, p_beta=0.5, q_beta=0.5, alpha=1.0, beta_gamma=1.0, ncatG=10, pi=None):
         self.kappa = kappa
         self.p0 = float(np.clip(p0, 1e-6, 1 - 1e-6))
@@ -263,8 +277,10 @@ class M9CodonModel(_SiteClassModel):
         self.pi = _normalise_pi(pi)
 
     def get_site_classes(self):
-        from scipy.stats import beta, gamma
         K = self.ncatG
+        if self.c_quantiles:
+            return [1.0 / K] * K, list(_mixture_quantiles_c("M9", (self.p0, self.p_beta, self.q_beta, self.alpha, self.beta_gamma), K))
+        from scipy.stats import beta, gamma
         cdf = lambda x: (self.p0 * beta.cdf(x, self.p_beta, self.q_beta)
                          + (1 - self.p0) * gamma.cdf(x, self.alpha, scale=1.0 / self.beta_gamma))
         return [1.0 / K] * K, _mixture_quantiles(cdf, K)

@@ -205,6 +205,14 @@ int crab_eval_codon_class_posteriors(crab_engine *e, int B, int K, const double 
  * (kind 1: M5, :892-899), shape parameters floored at 0.005 like the reference (:570-571, :864-865).  Replaces the
  * scipy.stats ppf calls (about 1 ms per objective call in the reference).  Host only. */
 int crab_discretise_omega(int kind, double a, double b, int K, double *omegas_out);
+/* The same step for the two models whose classes discretise a MIXTURE of two distributions, M6 and M9 (models/codon.py:
+ * 982-1020 and 1183-1222): omegas_out[j] is the root of cdf(x) = (2j+1)/(2K) on [1e-4, 99], found by Brent's method as
+ * scipy.optimize.brentq runs it with its default tolerances (what the reference calls), or the reference's fallback 10 p
+ * where the CDF does not change sign over that bracket.  kind 2 (M6): params = {p0, alpha1, beta1, alpha2}, cdf = p0
+ * Gamma(alpha1, rate beta1) + (1 - p0) Gamma(alpha2, rate alpha2); kind 3 (M9): params = {p0, p_beta, q_beta, alpha,
+ * beta_gamma}, cdf = p0 Beta(p_beta, q_beta) + (1 - p0) Gamma(alpha, rate beta_gamma); parameters clamped like the
+ * reference's constructors.  Host only. */
+int crab_discretise_omega_mixture(int kind, const double *params, int n_params, int K, double *omegas_out);
 /* Model A's class frequencies [4] and Qfactors {background, foreground} as crab_eval_codon_branch_site computes them
  * (codon_branch_site.py:108-231).  Host only. */
 int crab_model_a_quantities(double kappa, double omega0, double omega2, double p0, double p1, const double *pi,

@@ -411,6 +411,50 @@ def test_quantile_functions_against_scipy_over_the_optimisers_range():
         discretise_omega("beta", np.nan, 1.0, 5)
 
 
+@pytest.mark.parametrize("name,kind,keys", [("lysozyme_m6", "M6", ("p0", "alpha1", "beta1", "alpha2")),
+                                            ("lysozyme_m9", "M9", ("p0", "p_beta", "q_beta", "alpha", "beta_gamma"))])
+def test_mixture_quantiles_in_c_match_the_reference_fixtures(name, kind, keys):
+    """M6 / M9 discretise a mixture CDF with scipy.optimize.brentq (models/codon.py:982-1020, 1183-1222): the fixtures' class
+    omegas are the reference's own output; the C restatement of Brent's iteration lands on the same digits (2e-11 relative is
+    the bar the beta / gamma quantiles meet; brentq's own xtol is 2e-12 absolute)."""
+    import json
+    from crabml_amd.engine import discretise_omega_mixture
+    c = load_case(name)
+    par = json.loads(str(c["params_json"]))
+    got = discretise_omega_mixture(kind, [par[k] for k in keys], par["ncatG"])
+    ref = c["omegas"][: par["ncatG"]]
+    assert np.abs(got / ref - 1.0).max() <= 2e-11
+    assert np.all(np.diff(got) > 0)
+
+
+def test_mixture_quantiles_against_the_scipy_route_over_the_optimisers_range():
+    """Random parameters inside the optimisers' bounds: against crabml_amd.models' scipy route (the reference's expression:
+    brentq on p0 F1 + (1 - p0) F2 - p over [1e-4, 99], fallback 10 p).  Both routes stop within brentq's xtol = 2e-12 of the
+    root; where a branch of the iteration flips on the last bits of a CDF value they stop at different points inside it."""
+    from crabml_amd import models
+    from crabml_amd.engine import discretise_omega_mixture
+    rng = np.random.default_rng(11)
+    n_fallback = 0
+    for _ in range(60):
+        p0 = rng.uniform(0.001, 0.999)
+        a = np.exp(rng.uniform(np.log(0.005), np.log(99.0), 4))
+        for kind, model, params in (("M6", models.M6CodonModel(2.0, p0, a[0], a[1], a[2]), [p0, a[0], a[1], a[2]]),
+                                    ("M9", models.M9CodonModel(2.0, p0, a[0], a[1], a[2], a[3]), [p0, a[0], a[1], a[2], a[3]])):
+            ref = np.array(model.get_site_classes()[1])
+            got = discretise_omega_mixture(kind, params, 10)
+            p = (2.0 * np.arange(10) + 1.0) / 20.0
+            n_fallback += int(np.sum(ref == p * 10))
+            assert np.array_equal(got == p * 10, ref == p * 10)          # the reference's fallback, on the same classes
+            assert np.abs(got - ref).max() <= 4e-12 + 1e-13 * ref.max()
+    assert n_fallback > 0                                               # (steep mixtures put the first quantiles below 1e-4)
+    # the constructors' clamps (models/codon.py:966-971, 1168-1172), and bad arguments
+    assert np.array_equal(discretise_omega_mixture("M6", [2.0, 1e-9, 1.0, 1.0], 5), discretise_omega_mixture("M6", [1 - 1e-6, 0.005, 1.0, 1.0], 5))
+    with pytest.raises(ValueError):
+        discretise_omega_mixture("M9", [0.5, 1.0, 1.0, 1.0], 5)         # M9 takes five parameters
+    with pytest.raises(ValueError):
+        discretise_omega_mixture("M6", [0.5, np.nan, 1.0, 1.0], 5)
+
+
 def test_host_worker_pool_serves_concurrent_callers():
     """map_genes drives several engines from several host threads: their parallel loops share one pool."""
     from crabml_amd import _lib
