@@ -168,6 +168,55 @@ def target_workload(device, with_cpu=True, evals=8, cpu_sample=1000):
     return out
 
 
+def target_workload_sharded(rank, world, local_rank, data_group, evals=8):
+    """The north_star target as the north_star states it: M8, 500 taxa x 50 000 codons, the site patterns of ONE alignment
+    sharded over the N GPUs of this run (strong scaling; rank r owns slice r of the pattern list in the engine's shard order,
+    every evaluation ends with the rank-ordered sum of the N partial log-likelihoods).  Every rank returns; rank 0's dict is
+    the one reported."""
+    import torch
+    import torch.distributed as dist
+    from crabml_amd import models, synth
+    from crabml_amd.dist import all_gather_doubles, ordered_sum, sharded_engine
+    n_taxa, n_sites = 500, 50000
+    case = synth.make_case("M8", n_taxa, n_sites, seed=6)
+    K = len(case.proportions)
+    Qs = []
+    for i in range(evals + 2):
+        m = models.M8CodonModel(kappa=case.kappa * (1.0 + 1e-7 * i), p0=0.9, p_beta=0.7, q_beta=1.5, omega_s=2.5, ncatG=10, pi=case.pi)
+        Qs.append(np.ascontiguousarray(np.stack(m.get_Q_matrices())))
+    eng = sharded_engine(case.codes, case.parent, case.leaf_node_ids, rank, world, device=local_rank)
+    try:
+        for Q in Qs[:2]:
+            lnL = ordered_sum(eng.site_classes(Q, case.proportions, case.pi, case.branch_lengths), group=data_group)
+        prune = []
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for Q in Qs[2:]:
+            lnL = ordered_sum(eng.site_classes(Q, case.proportions, case.pi, case.branch_lengths), group=data_group)
+            prune.append(eng.last_timing()[1])
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item()) / evals
+        dense, _ = eng.last_work()
+        per_rank = all_gather_doubles([float(np.mean(prune)), float(dense), float(eng.n_patterns)], group=data_group)
+    finally:
+        eng.close()
+    updates_per_eval = n_sites * (case.n_nodes - 1) * K
+    return {"workload": "north_star target: M8 (11 classes), 500 taxa x 50000 codons, site patterns of ONE alignment sharded over "
+                        f"{world} MI355X (strong scaling), tree length %.2f subst/codon" % case.tree_length,
+            "n_gpus": world, "scaling": "strong", "lnl_evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt,
+            "cl_updates_per_s": updates_per_eval / dt, "lnL": lnL,
+            "prune_kernel_ms_per_rank": [float(x) for x in per_rank[:, 0]],
+            "executed_dense_updates_per_rank": [int(x) for x in per_rank[:, 1]],
+            "patterns_per_rank": [int(x) for x in per_rank[:, 2]],
+            "note": "patterns are numbered in shard order (consensus codon of the column, leaves that differ from it), so that a "
+                    "slice shows about 1/N of every clade's distinct sub-patterns; one all-gather of one double per rank and evaluation"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +423,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case)
     eng.close()
+    if world > 1 and not args.no_target:
+        # the north_star number itself: ONE 500 x 50 000 alignment sharded over the ranks of this run (all ranks take part)
+        tw = target_workload_sharded(rank, world, local_rank, data_group)
+        if rank == 0:
+            out["target_workload"] = tw
     if rank == 0:
         if world == 1 and not args.no_target:
             out["target_workload"] = target_workload(local_rank, with_cpu=not args.no_cpu_baseline)

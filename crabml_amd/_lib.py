@@ -53,6 +53,7 @@ SIGNATURES = {
     "crab_eval_codon_branch_site": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, bp, C.c_int, C.c_uint, dp]),
     "crab_build_site_class_q_matrices": (C.c_int, [C.c_int, C.c_double, dp, dp, dp, dp]),
     "crab_discretise_omega": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, dp]),
+    "crab_plan_clade_work": (C.c_int, [C.c_int, ip, ip, ip, C.c_int, ip, C.c_int64, C.c_int, C.POINTER(C.c_int), lp, lp, lp]),
     "crab_discretise_omega_mixture": (C.c_int, [C.c_int, dp, C.c_int, C.c_int, dp]),
     "crab_model_a_quantities": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]),
     "crab_last_timing": (C.c_int, [vp, dp, dp, dp]),

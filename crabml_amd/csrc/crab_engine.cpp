@@ -1393,7 +1393,8 @@ uint64_t mix64(uint64_t h, uint64_t v)
 
 // Collapses identical alignment columns.  cols: column-major byte image [n_sites][n_leaves] (output),
 // site_to_pat[s] = pattern id, first_site[p] = first site showing pattern p, count[p] = multiplicity.
-// Pattern ids follow first appearance, so the pattern order (and every sum over it) is deterministic.
+// Pattern ids follow the shard order below (compress != 0; sites as they come otherwise): a function of the alignment alone, so
+// the pattern order (and every sum over it) is deterministic and the same on every rank.
 void compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states, int compress,
                        std::vector<uint8_t> &cols, std::vector<int64_t> &site_to_pat, std::vector<int64_t> &first_site,
                        std::vector<double> &count)
@@ -1439,6 +1440,38 @@ void compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int 
             count[found] += 1.0;
             site_to_pat[s] = found;
         }
+        // Shard order.  Slices of the pattern list go to different GPUs, and what a GPU executes with clade tables grows with
+        // the distinct sub-patterns its slice shows in every clade: in first-appearance order a 1/8 slice of the target
+        // workload (M8, 500 taxa x 50 000 codons) executes 0.20 of the whole alignment's products, because every slice meets
+        // nearly all of the common sub-patterns.  Patterns are therefore numbered by (consensus codon of the column, number
+        // of leaves that differ from it, first appearance): columns that agree on most leaves -- and with them on most
+        // clades' sub-patterns -- become neighbours, a 1/8 slice executes 0.145 (scripts/shard_orders.py; a key built from
+        // the tree's own clades did no better).  A function of the alignment alone, so every rank numbers alike.
+        const int64_t n_pat = (int64_t)first_site.size();
+        std::vector<int64_t> key(n_pat), order(n_pat);
+        std::vector<int> freq(n_states + 1);
+        for (int64_t p = 0; p < n_pat; ++p) {
+            const uint8_t *col = &cols[(size_t)first_site[p] * n_leaves];
+            std::fill(freq.begin(), freq.end(), 0);
+            for (int r = 0; r < n_leaves; ++r) ++freq[col[r]];
+            int cons = n_states;
+            for (int c = 0; c < n_states; ++c)
+                if (freq[c] > (cons == n_states ? 0 : freq[cons])) cons = c;
+            const int64_t n_diff = n_leaves - freq[cons];
+            key[p] = ((int64_t)cons << 32) | n_diff;
+            order[p] = p;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+        std::vector<int64_t> new_id(n_pat), first2(n_pat);
+        std::vector<double> count2(n_pat);
+        for (int64_t k = 0; k < n_pat; ++k) {
+            new_id[order[k]] = k;
+            first2[k] = first_site[order[k]];
+            count2[k] = count[order[k]];
+        }
+        first_site.swap(first2);
+        count.swap(count2);
+        for (int64_t s = 0; s < n_sites; ++s) site_to_pat[s] = new_id[site_to_pat[s]];
     } else {
         first_site.resize(n_sites);
         count.assign(n_sites, 1.0);
@@ -3216,6 +3249,39 @@ int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_
                     for (int64_t u = 0; u < cl.U; ++u) sub_codes_out[(size_t)r * cl.U + u] = lvl[(size_t)r * npp + u];
             }
         }
+    });
+}
+
+int crab_plan_clade_work(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                         const int32_t *codes, int64_t n_patterns, int n_states, int *n_clades, int64_t *sub_patterns,
+                         int64_t *products, int64_t *whole_walk_products)
+{
+    return guarded(nullptr, [&] {
+        if (!codes || n_patterns < 1 || n_states < 1 || n_states > NS - 1) fail(CRAB_ERR_ARG, "crab_plan_clade_work: bad arguments");
+        TreeProgram tp;
+        build_tree(&tp, n_nodes, node_ids, parents, leaf_node_ids, n_leaves);
+        const int tile = prune_tile_width();
+        const int64_t npp = (n_patterns + tile - 1) / tile * tile;
+        std::vector<uint8_t> img((size_t)n_leaves * npp, (uint8_t)n_states);
+        for (int r = 0; r < n_leaves; ++r)
+            for (int64_t p = 0; p < n_patterns; ++p) {
+                const int32_t c = codes[(size_t)r * n_patterns + p];
+                img[(size_t)r * npp + p] = (c >= 0 && c < n_states) ? (uint8_t)c : (uint8_t)n_states;
+            }
+        CladeTables ct;
+        std::vector<uint32_t> idx;
+        std::vector<uint8_t> alt;
+        plan_clade_tables(&tp, img.data(), n_leaves, n_patterns, npp, n_states, ct, idx, alt);
+        int64_t sub = 0, prod = 0;
+        for (const auto &cl : ct.clades) {
+            sub += cl.U;
+            prod += (int64_t)cl.prog.info.n_gemm * cl.tiles * tile;
+        }
+        prod += (ct.clades.empty() ? tp.n_gemm_edges : (int64_t)ct.main.info.n_gemm) * n_patterns;
+        if (n_clades) *n_clades = (int)ct.clades.size();
+        if (sub_patterns) *sub_patterns = sub;
+        if (products) *products = prod;
+        if (whole_walk_products) *whole_walk_products = tp.n_gemm_edges * n_patterns;
     });
 }
 

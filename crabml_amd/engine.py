@@ -451,6 +451,22 @@ def compile_clade_tables(parents, leaf_node_ids, codes, n_states=61, node_ids=No
     return main, [one(j)[2] for j in range(n_cl)]
 
 
+def plan_clade_work(parents, leaf_node_ids, codes, n_states=61, node_ids=None):
+    """(clades, distinct sub-patterns, products per class with clade tables, products per class of whole walks) for the
+    patterns in ``codes`` [n_leaves, n_patterns] (crab_plan_clade_work; host only)."""
+    lib = L.load()
+    par, parp = L.i32(parents)
+    leaf, leafp = L.i32(leaf_node_ids)
+    cod, codp = L.i32(codes)
+    idp = None
+    if node_ids is not None:
+        ids, idp = L.i32(node_ids)
+    n_cl, sub, prod, whole = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64()
+    L.check(lib.crab_plan_clade_work(len(par), idp, parp, leafp, len(leaf), codp, cod.shape[1], int(n_states), C.byref(n_cl),
+                                     C.byref(sub), C.byref(prod), C.byref(whole)))
+    return n_cl.value, sub.value, prod.value, whole.value
+
+
 def compress_patterns(codes, n_states=61):
     lib = L.load()
     codes_, cp = L.i32(codes)

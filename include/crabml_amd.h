@@ -300,6 +300,12 @@ int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_
                               const int32_t *codes, int64_t n_patterns, int n_states, int part, int32_t *ops_out, int ops_capacity,
                               int *n_ops, int *n_clades, int *clade_root, int *parent_clade, int *wide_row, int64_t *n_sub_patterns,
                               uint32_t *index_out, int32_t *sub_codes_out);
+/* What the clade-table plan of a set of patterns executes, per site class (host only; for tests and for choosing how an
+ * alignment is cut into shards): the clades tabled, the sum of their distinct sub-patterns, the products of one evaluation
+ * (clade programs over padded sub-patterns + main program per pattern) and the products of whole walks. */
+int crab_plan_clade_work(int n_nodes, const int32_t *node_ids, const int32_t *parents, const int32_t *leaf_node_ids, int n_leaves,
+                         const int32_t *codes, int64_t n_patterns, int n_states, int *n_clades, int64_t *sub_patterns,
+                         int64_t *products, int64_t *whole_walk_products);
 /* Site-pattern compression as crab_set_alignment(compress=1) performs it. Outputs may be NULL. */
 int crab_compress_patterns(const int32_t *codes, int n_leaves, int64_t n_sites, int n_states,
                            int64_t *site_to_pattern, double *pattern_weight, int64_t *first_site,

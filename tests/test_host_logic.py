@@ -192,7 +192,16 @@ def test_pattern_compression():
     s2p, w, first = compress_patterns(c["sequences"])
     assert len(w) == 86 and w.sum() == 130          # PAML's own pattern count for this alignment (lnf header)
     np.testing.assert_array_equal(c["sequences"][:, first][:, s2p], c["sequences"])
-    assert list(first) == sorted(first)             # patterns are numbered by first appearance
+    # patterns are numbered in shard order: by (consensus codon of the column, leaves that differ from it, first appearance)
+    seq = c["sequences"]
+    keys = []
+    for p in range(len(w)):
+        col = seq[:, first[p]]
+        cnt = np.bincount(col[(col >= 0) & (col < 61)], minlength=61)
+        cons = int(cnt.argmax()) if cnt.max() > 0 else 61
+        keys.append((cons, int(len(col) - (cnt[cons] if cons < 61 else np.sum((col < 0) | (col >= 61)))), int(first[p])))
+    assert keys == sorted(keys)
+    assert all(first[p] == np.flatnonzero(s2p == p)[0] for p in range(len(w)))   # and represented by their first column
     # missing-data codes are one symbol
     e = load_case("synthetic_edge")
     seq = e["sequences"].copy()
