@@ -118,6 +118,7 @@ double now_ms()
 }  // namespace
 
 uint64_t hash_words(const void *p, size_t bytes, uint64_t seed);
+void hash_words2(const void *p, size_t bytes, uint64_t seed, uint64_t out[2]);
 
 namespace crab {
 // for entry points that live in other source files (crab_noalloc.hip): the message crab_last_error(NULL) returns
@@ -134,9 +135,9 @@ void set_global_error(const std::string &msg) { g_last_error = msg; }
 struct EigPool {
     struct Entry {
         bool used = false, by_params = false;
-        uint64_t h = 0, stamp = 0;
+        uint64_t h = 0, h2 = 0, stamp = 0;   // (h, h2): two 64-bit digests of one pass over Q (content keys)
         double kappa = 0, omega = 0;
-        std::vector<double> Q, pi;   // Q only for content keys
+        std::vector<double> Q, pi;   // Q only for content keys, and only kept when hits are confirmed byte for byte
     };
     static constexpr size_t SOFT_MAX = 4096;  // x 66 KB = 270 MB of HBM; least recently used entries make room beyond it
     std::vector<Entry> slots;
@@ -146,12 +147,25 @@ struct EigPool {
     size_t cap = 0;
     uint64_t clock = 0;
 
-    int find_content(uint64_t h, const double *Q, const double *pi, int n)
+    // A matrix passed by value is recognised by the 128 bits of (h, h2) and by pi -- as the one-shot functions recognise an
+    // alignment.  Round 2 confirmed every hit byte for byte against a host copy of the matrix: for the 1 998 matrices of a
+    // free-ratio call that meant reading 59 MB twice (hash, then compare) per evaluation, 1.1 ms of a 1.8 ms call whose
+    // device part takes 0.6.  CRAB_EIG_CONFIRM=1 brings the comparison back.
+    static bool confirm_hits()
+    {
+        static const bool on = [] {
+            const char *sv = std::getenv("CRAB_EIG_CONFIRM");
+            return sv && sv[0] && sv[0] != '0';
+        }();
+        return on;
+    }
+    int find_content(uint64_t h, uint64_t h2, const double *Q, const double *pi, int n)
     {
         auto r = index.equal_range(h);
         for (auto it = r.first; it != r.second; ++it) {
             Entry &en = slots[it->second];
-            if (!en.by_params && std::memcmp(en.Q.data(), Q, sizeof(double) * n * n) == 0 && std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0) {
+            if (!en.by_params && en.h2 == h2 && (!confirm_hits() || std::memcmp(en.Q.data(), Q, sizeof(double) * n * n) == 0) &&
+                std::memcmp(en.pi.data(), pi, sizeof(double) * n) == 0) {
                 en.stamp = clock;
                 return it->second;
             }
@@ -1628,8 +1642,13 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     ++pool.clock;
     std::vector<int32_t> uniq_of(pl.n_eig);       // rate matrix -> slot among this call's distinct eigensystems
     std::vector<int> uniq_src;                    // slot -> first rate matrix showing it
-    std::vector<uint64_t> qhash(pl.n_eig);
+    std::vector<uint64_t> qhash(pl.n_eig), qhash2(pl.n_eig, 0);
     const uint64_t pih = hash_words(pi, sizeof(double) * n, 11);
+    auto digest = [&](int i) {
+        uint64_t d[2];
+        hash_words2(Q + (size_t)i * n * n, sizeof(double) * n * n, pih, d);
+        qhash[i] = d[0], qhash2[i] = d[1];
+    };
     if (by_params) {                              // the caller lists distinct (kappa, omega) pairs
         for (int i = 0; i < pl.n_eig; ++i) {
             const double kw[2] = {pl.kw[i].first, pl.kw[i].second};
@@ -1639,11 +1658,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         }
     } else {
         if ((size_t)pl.n_eig * n * n * sizeof(double) < (1u << 20))   // a few matrices: cheaper than waking the pool (measured)
-            for (int i = 0; i < pl.n_eig; ++i) qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih);
+            for (int i = 0; i < pl.n_eig; ++i) digest(i);
         else
-            parallel_for(pl.n_eig, [&](int i) { qhash[i] = hash_words(Q + (size_t)i * n * n, sizeof(double) * n * n, pih); });
-        // group by hash, then confirm every presumed duplicate against its representative byte for byte, in parallel
-        // (a batch of B vectors repeats almost all of its B x K matrices); a hash collision falls back to the exact search
+            parallel_for(pl.n_eig, digest);
+        // group by digest (a batch of B vectors repeats almost all of its B x K matrices); with CRAB_EIG_CONFIRM every presumed
+        // duplicate is also compared with its representative byte for byte, in parallel, and a collision falls back to the
+        // exact search
         auto group = [&](bool exact) {
             uniq_src.clear();
             std::unordered_map<uint64_t, std::vector<int>> seen;
@@ -1652,7 +1672,8 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                 auto &cands = seen[qhash[i]];
                 int slot = -1;
                 for (int u : cands)
-                    if (!exact || std::memcmp(Q + (size_t)uniq_src[u] * n * n, Qi, sizeof(double) * n * n) == 0) {
+                    if (qhash2[uniq_src[u]] == qhash2[i] &&
+                        (!exact || std::memcmp(Q + (size_t)uniq_src[u] * n * n, Qi, sizeof(double) * n * n) == 0)) {
                         slot = u;
                         break;
                     }
@@ -1666,7 +1687,7 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         };
         group(false);
         const int dupes = pl.n_eig - (int)uniq_src.size();
-        if (dupes > 0) {
+        if (dupes > 0 && EigPool::confirm_hits()) {
             std::atomic<int> collisions{0};
             auto check = [&](int i) {
                 const int rep = uniq_src[uniq_of[i]];
@@ -1686,12 +1707,11 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     auto look_up = [&](int u) {
         const int i = uniq_src[u];
         pool_slot[u] = by_params ? pool.find_params(qhash[i], pl.kw[i].first, pl.kw[i].second, pi, n)
-                                 : pool.find_content(qhash[i], Q + (size_t)i * n * n, pi, n);
+                                 : pool.find_content(qhash[i], qhash2[i], Q + (size_t)i * n * n, pi, n);
     };
-    // A hit is confirmed byte for byte against the cached matrix: with the 1 998 matrices of a free-ratio call that is 59 MB to
-    // read, 2 ms on one thread -- four times the device's share of the evaluation.  Look-ups only read the index, and distinct
-    // matrices stamp distinct entries, so they run side by side.
-    if (!by_params && (size_t)n_uniq * n * n * sizeof(double) >= (1u << 20))
+    // (With CRAB_EIG_CONFIRM a hit is compared byte for byte with the cached matrix -- 59 MB for the 1 998 matrices of a
+    // free-ratio call -- and the look-ups run side by side: they only read the index, distinct matrices stamp distinct entries.)
+    if (!by_params && EigPool::confirm_hits() && (size_t)n_uniq * n * n * sizeof(double) >= (1u << 20))
         parallel_for(n_uniq, look_up);
     else
         for (int u = 0; u < n_uniq; ++u) look_up(u);
@@ -2414,13 +2434,14 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         en.used = true;
         en.by_params = by_params;
         en.h = qhash[i];
+        en.h2 = qhash2[i];
         en.stamp = pool.clock;
         en.pi.assign(pi, pi + n);
         if (by_params) {
             en.kappa = pl.kw[i].first;
             en.omega = pl.kw[i].second;
         } else {
-            en.Q.assign(Q + (size_t)i * n * n, Q + (size_t)(i + 1) * n * n);
+            if (EigPool::confirm_hits()) en.Q.assign(Q + (size_t)i * n * n, Q + (size_t)(i + 1) * n * n);
         }
         pool.index.emplace(en.h, new_slots[j]);
     }
@@ -3778,7 +3799,7 @@ uint64_t hash_words(const void *p, size_t bytes, uint64_t seed)
 }
 
 // two 64-bit digests of the same pass (the second folds the four lanes in another order with other constants)
-static void hash_words2(const void *p, size_t bytes, uint64_t seed, uint64_t out[2])
+void hash_words2(const void *p, size_t bytes, uint64_t seed, uint64_t out[2])
 {
     uint64_t l[4];
     size_t i;
