@@ -458,7 +458,7 @@ struct CladeTables {
         int root = -1;               // the clade's root node
         int parent = -1;             // the clade whose program gathers from this one's table, -1: the main program
         int level = 1;               // 1: no clade inside; a clade's program runs after those of all lower levels
-        int row = 0;                 // its wide row among those of its consumer's launch: alignment row aln_rows + row there
+        int row = 0;                 // its wide row (absolute): alignment row aln_rows + row in its consumer's program
         int64_t U = 0, tiles = 0;    // distinct sub-patterns, and ceil(U / tile width)
         int slot_off = 0;            // first 64 KiB slot of its table inside one class's run of table slots
         PathProgram prog;            // its subtree with inner clades as table leaves, the product on its root's branch, the store
@@ -493,6 +493,7 @@ struct crab_engine : TreeProgram {
         int list_off = 0, n_entries = 0;      // its entries of the program list
         int64_t items_off = 0, n_items = 0;   // its work items
         int grid = 0;                          // its workgroups
+        bool merged = false;                   // all levels in this launch: items wait for the tables they gather from
         int64_t bounds[9] = {0};
     };
     std::vector<CladeLaunch> dev_clade_launches;
@@ -516,7 +517,8 @@ struct crab_engine : TreeProgram {
     DevBuf<DevOp> d_ops;
     DevBuf<uint8_t> d_codes;
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
-    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_work_ctr;
+    DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_work_ctr, d_deps;
+    int dev_n_prog = 0;
     DevBuf<ProgHdr> d_items;
     DevBuf<uint32_t> d_idx32;
     DevBuf<uint8_t> d_codes_alt;
@@ -555,7 +557,7 @@ struct crab_engine : TreeProgram {
         eig_pool.release();
         d_ops.release(); d_codes.release(); d_weights.release(); d_small.release(); d_P.release();
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
-        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_work_ctr.release(); d_idx32.release(); d_codes_alt.release();
+        d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_work_ctr.release(); d_deps.release(); d_idx32.release(); d_codes_alt.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
         h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release(); d_eig_status.release(); h_eig_status.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
@@ -1243,6 +1245,9 @@ void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows,
     for (auto &cl : ct.clades) cl.row = (int)rows_in[launch_of_consumer(cl.parent)]++;
     ct.row_begin.assign(ct.n_levels + 2, 0);
     for (int l = 0; l <= ct.n_levels; ++l) ct.row_begin[l + 1] = ct.row_begin[l] + rows_in[l];
+    // (rows are absolute from here on: every launch reads the wide rows through the same base, so that clade programs of
+    // several levels can share one launch)
+    for (auto &cl : ct.clades) cl.row += (int)ct.row_begin[launch_of_consumer(cl.parent)];
     idx.assign((size_t)ct.row_begin[ct.n_levels + 1] * npp, 0u);
     alt.assign((size_t)ct.n_levels * aln_rows * npp, (uint8_t)n_states);
     auto rows_below = [&](int c) {
@@ -1262,7 +1267,7 @@ void plan_clade_tables(const TreeProgram *e, const uint8_t *codes, int aln_rows,
     for (int j = 0; j < n_cl; ++j) {
         CladeTables::Clade &cl = ct.clades[j];
         // where its consumer looks it up: per pattern (main program) or per distinct sub-pattern of the consuming clade
-        uint32_t *row = idx.data() + (size_t)(ct.row_begin[launch_of_consumer(cl.parent)] + cl.row) * npp;
+        uint32_t *row = idx.data() + (size_t)cl.row * npp;
         if (cl.parent < 0) {
             for (int64_t p = 0; p < n_pat; ++p) row[p] = (uint32_t)ids[cl.root][p];
         } else {
@@ -1604,6 +1609,21 @@ bool path_updates_disabled()
 bool tree_parts_disabled()
 {
     const char *sv = std::getenv("CRAB_NO_TREE_PARTS");
+    return sv && sv[0] && sv[0] != '0';
+}
+// CRAB_STATIC_ITEMS=1: the items of a launch are dealt round-robin to its workgroups, as in rounds 1-2 (read once)
+bool dynamic_items_enabled()
+{
+    static const bool on = [] {
+        const char *sv = std::getenv("CRAB_STATIC_ITEMS");
+        return !(sv && sv[0] && sv[0] != '0');
+    }();
+    return on;
+}
+// CRAB_CLADE_LEVEL_LAUNCHES=1: one launch per level of clade nesting, as in round 2 (read when an engine plans its programs)
+bool clade_level_launches_forced()
+{
+    const char *sv = std::getenv("CRAB_CLADE_LEVEL_LAUNCHES");
     return sv && sv[0] && sv[0] != '0';
 }
 bool clade_tables_disabled()
@@ -1988,6 +2008,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             int32_t prog, tile0, n;
         };
         std::vector<ItemRef> items;                 // clade launches: (program, first tile, tiles) per work item
+        std::vector<int32_t> dep_recs;              // merged clade launch: per program, the tables it waits for
+        // CRAB_CLADE_LEVEL_LAUNCHES=1: one launch per nesting level, as in round 2.  The merged launch needs the dynamic hand-out
+        // (an item is only ever held by a workgroup that is running) and a device that deals workgroups to XCDs by number.
+        const bool merged_clade_launch = !clade_level_launches_forced() && dynamic_items_enabled() && prune_device_has_all_xcds(e->device);
         if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
@@ -2038,76 +2062,197 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
                             resolve_program(pp.ops, pk_c.data(), false, po);
                             po[pp.ops.size() - 1].mat = table_mat(t, consumer);   // the table store
                             header(prog, pp.info, c % Kg, 1);
-                            hdrs[prog].alt_codes = 1;
+                            // bit 0: leaf rows come from codes_alt; bits 2..: the clade's level (its slice of codes_alt); bit 1 (set
+                            // below for a merged launch): the program waits for the tables of the clades inside it
+                            hdrs[prog].alt_codes = 1 | ((ct.clades[consumer].level - 1) << 2);
                         }
                     }
                     e->dev_gemm_per_pat += ct.main.info.n_gemm;
                     e->dev_leaf_per_pat += ct.main.info.n_leaf;
                 }
-                // one launch per level: class-major (one class's matrices stay together), clades with most products first
-                e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
-                for (int l = 0; l < ct.n_levels; ++l) {
-                    crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+                // Work items: runs of consecutive tiles of one (class, clade) -- a cyclic program pays its prologue (item -> header
+                // -> ops, codes -> columns -> operand image: a chain of dependent loads) once per item, later tiles start from what
+                // the previous tile's last product requested.
+                struct Item {
+                    int32_t prog, tile0, n, level;
+                    double w;
+                };
+                auto env_w = [](const char *name, double dflt) {
+                    const char *sv = std::getenv(name);
+                    return sv && sv[0] ? std::atof(sv) : dflt;
+                };
+                // predicted time of an item in products: a prologue, and per tile its products and a sixth of a product for the
+                // rest (fitted to per-workgroup busy times, scripts/gpu_prof_phases.sh with -DCRAB_CLOCK)
+                const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
+                const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device);
+                auto items_of = [&](int t, int j, int64_t run_len, std::vector<Item> &out) {
+                    const ProgInfo &in = ct.clades[j].prog.info;
+                    const int64_t tiles = ct.clades[j].tiles;
+                    const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
+                    for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
+                        const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
+                        out.push_back({(int32_t)(pl.K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo), ct.clades[j].level,
+                                       w_item + (double)(hi - lo) * (in.n_gemm + w_tile)});
+                    }
+                };
+                int64_t run_env = 0;
+                if (const char *sv = std::getenv("CRAB_CLADE_ITEM_TILES")) run_env = std::max(1, std::min(64, std::atoi(sv)));
+                for (int t = 0; t < n_tab; ++t)
+                    for (int j = 0; j < n_cl; ++j) e->dev_gemm_extra += (int64_t)ct.clades[j].prog.info.n_gemm * ct.clades[j].tiles * prune_tile_width();
+                // A clade with more inner clades than a dependency record holds (6) cannot wait for them inside a launch.
+                bool merge = merged_clade_launch;
+                for (int j = 0; j < n_cl && merge; ++j) {
+                    int inner = 0;
+                    for (int c2 = 0; c2 < n_cl; ++c2) inner += ct.clades[c2].parent == j;
+                    merge = inner <= 6;
+                }
+                dep_recs.clear();
+                if (merge) {
+                    // ONE launch for the clade programs of all levels.  A unit = one class's copy of an outermost clade with every
+                    // clade nested inside it: tables are written and read inside a unit only.  Units are dealt to the XCDs by
+                    // predicted work (largest first, each to the XCD with the least so far), so a table and the counter that
+                    // announces it stay in one XCD's L2 -- nothing in the launch depends on coherence between XCDs.  An XCD's
+                    // items are ordered by level, then longest first; the kernel hands them out in that order and an item whose
+                    // program gathers from inner clades' tables waits for their counters (PruneArgs::deps, ::done): every item it
+                    // waits for sits earlier in the same queue, and items of level 1 wait for nothing, so by induction over the
+                    // levels every wait ends.
+                    int64_t all_tiles = 0;
+                    for (int j = 0; j < n_cl; ++j) all_tiles += ct.clades[j].tiles;
+                    const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, all_tiles * n_tab / (6 * slots)));
+                    std::vector<int> outer_of(n_cl);
+                    for (int j = 0; j < n_cl; ++j) {
+                        int r = j;
+                        while (ct.clades[r].parent >= 0) r = ct.clades[r].parent;
+                        outer_of[j] = r;
+                    }
+                    struct Unit {
+                        std::vector<Item> its;
+                        double w = 0.0;
+                    };
+                    std::vector<Unit> units;
+                    std::vector<int> unit_of(n_cl, -1);
+                    for (int t = 0; t < n_tab; ++t) {
+                        std::fill(unit_of.begin(), unit_of.end(), -1);
+                        for (int j = 0; j < n_cl; ++j) {
+                            int &u = unit_of[outer_of[j]];
+                            if (u < 0) {
+                                u = (int)units.size();
+                                units.emplace_back();
+                            }
+                            const size_t before = units[u].its.size();
+                            items_of(t, j, run_len, units[u].its);
+                            for (size_t i = before; i < units[u].its.size(); ++i) units[u].w += units[u].its[i].w;
+                        }
+                    }
+                    std::vector<int> by_w(units.size());
+                    for (size_t u = 0; u < units.size(); ++u) by_w[u] = (int)u;
+                    std::stable_sort(by_w.begin(), by_w.end(), [&](int p, int q) { return units[p].w > units[q].w; });
+                    std::vector<std::vector<Item>> of_xcd(8);
+                    double load[8] = {0};
+                    for (int u : by_w) {
+                        const int x = (int)(std::min_element(load, load + 8) - load);
+                        load[x] += units[u].w;
+                        of_xcd[x].insert(of_xcd[x].end(), units[u].its.begin(), units[u].its.end());
+                    }
+                    e->dev_clade_launches.assign(1, crab_engine::CladeLaunch{});
+                    crab_engine::CladeLaunch &cl = e->dev_clade_launches[0];
                     cl.list_off = (int)lists.size();
                     cl.items_off = (int64_t)items.size();
-                    std::vector<int> order;
-                    for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
-                    std::stable_sort(order.begin(), order.end(),
-                                     [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
-                    // Work items: runs of consecutive tiles of one (class, clade) -- a cyclic program pays its prologue (item ->
-                    // header -> ops, codes -> columns -> operand image: a chain of dependent loads, ~9 us) once per item, later
-                    // tiles start from what the previous tile's tail requested.  Runs are as long as the launch can afford while it
-                    // still has ~3 items per resident workgroup (CRAB_CLADE_ITEM_TILES sets the length instead; 1 = one tile per item).
-                    int64_t level_tiles = 0;
-                    for (int j : order) level_tiles += ct.clades[j].tiles;
-                    const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device);
-                    int64_t run_len = std::max<int64_t>(1, std::min<int64_t>(8, level_tiles * n_tab / (3 * slots)));
-                    if (const char *sv = std::getenv("CRAB_CLADE_ITEM_TILES")) run_len = std::max(1, std::min(64, std::atoi(sv)));
-                    struct Item {
-                        int32_t prog, tile0, n;
-                        double w;
-                    };
-                    auto env_w = [](const char *name, double dflt) {
-                        const char *sv = std::getenv(name);
-                        return sv && sv[0] ? std::atof(sv) : dflt;
-                    };
-                    const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
-
-                    std::vector<Item> its;
                     for (int t = 0; t < n_tab; ++t)
-                        for (int j : order) {
-                            lists.push_back(pl.K + t * n_cl + j);
-                            const ProgInfo &in = ct.clades[j].prog.info;
-                            const int64_t tiles = ct.clades[j].tiles;
-                            const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
-                            for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
-                                const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
-                                // predicted time in products: a prologue, and per tile its products and a sixth of a product for the
-                                // rest (fitted to per-workgroup busy times, scripts/gpu_prof_phases.sh with -DCRAB_CLOCK)
-                                its.push_back({(int32_t)(pl.K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo),
-                                               w_item + (double)(hi - lo) * (in.n_gemm + w_tile)});
-                            }
-                            e->dev_gemm_extra += (int64_t)in.n_gemm * tiles * prune_tile_width();
-                        }
+                        for (int j = 0; j < n_cl; ++j) lists.push_back(pl.K + t * n_cl + j);
                     cl.n_entries = (int)lists.size() - cl.list_off;
-                    cl.n_items = (int64_t)its.size();
-                    // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that share
-                    // an L2 walk the same matrices); inside a chunk the longest items first -- the kernel hands a chunk's items out in
-                    // order to whichever of the XCD's workgroups asks next, so the tail of the launch is a short item.
-                    double total = 0.0, acc = 0.0;
-                    for (const Item &it : its) total += it.w;
-                    int x = 1;
                     cl.bounds[0] = 0;
-                    for (size_t i = 0; i < its.size() && x < 8; ++i) {
-                        acc += its[i].w;
-                        while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
+                    for (int x = 0; x < 8; ++x) {
+                        std::stable_sort(of_xcd[x].begin(), of_xcd[x].end(),
+                                         [](const Item &p, const Item &q) { return p.level != q.level ? p.level < q.level : p.w > q.w; });
+                        for (const Item &it : of_xcd[x]) items.push_back({it.prog, it.tile0, it.n});
+                        cl.bounds[x + 1] = cl.bounds[x] + (int64_t)of_xcd[x].size();
                     }
-                    while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
-                    cl.grid = prune_grid_size((int64_t)its.size(), e->device);
-                    for (int c8 = 0; c8 < 8; ++c8)
-                        std::stable_sort(its.begin() + cl.bounds[c8], its.begin() + cl.bounds[c8 + 1],
-                                         [](const Item &p, const Item &q) { return p.w > q.w; });
-                    for (const Item &it : its) items.push_back({it.prog, it.tile0, it.n});
+                    cl.n_items = cl.bounds[8];
+                    cl.grid = prune_grid_size(cl.n_items, e->device);
+                    cl.merged = true;
+                    // one record per program: [n, program x 6, tiles needed x 6, 0, 0, 0]; behind them, per program, the tiles it
+                    // announces in all (PruneArgs::expect)
+                    dep_recs.assign((size_t)n_prog * 17, 0);
+                    for (int t = 0; t < n_tab; ++t)
+                        for (int j = 0; j < n_cl; ++j) {
+                            int32_t *d = dep_recs.data() + (size_t)(pl.K + t * n_cl + j) * 16;
+                            dep_recs[(size_t)n_prog * 16 + pl.K + t * n_cl + j] = (int32_t)ct.clades[j].tiles;
+                            for (int c2 = 0; c2 < n_cl; ++c2)
+                                if (ct.clades[c2].parent == j) {
+                                    d[1 + d[0]] = pl.K + t * n_cl + c2;
+                                    d[7 + d[0]] = (int32_t)ct.clades[c2].tiles;
+                                    ++d[0];
+                                }
+                            if (d[0] > 0) hdrs[pl.K + t * n_cl + j].alt_codes |= 2;
+                        }
+                    // What the kernel's waits rely on, checked here rather than found out on the device: every program's items sit
+                    // in one XCD's chunk, after all items of the programs it waits for, whose tiles add up to what it waits for.
+                    {
+                        std::vector<int64_t> first(n_prog, -1), last(n_prog, -1), tiles_of(n_prog, 0);
+                        std::vector<int> xcd_of(n_prog, -1);
+                        bool ok = true;
+                        for (int x = 0; x < 8; ++x)
+                            for (int64_t i = cl.bounds[x]; i < cl.bounds[x + 1]; ++i) {
+                                const ItemRef &it = items[(size_t)(cl.items_off + i)];
+                                ok = ok && it.prog >= pl.K && it.prog < n_prog && (xcd_of[it.prog] < 0 || xcd_of[it.prog] == x);
+                                if (!ok) break;
+                                xcd_of[it.prog] = x;
+                                if (first[it.prog] < 0) first[it.prog] = i;
+                                last[it.prog] = i;
+                                tiles_of[it.prog] += it.n;
+                            }
+                        for (int pr = pl.K; pr < n_prog && ok; ++pr) {
+                            const int32_t *d = dep_recs.data() + (size_t)pr * 16;
+                            ok = first[pr] >= 0 && d[0] >= 0 && d[0] <= 6 && tiles_of[pr] == ct.clades[(pr - pl.K) % n_cl].tiles;
+                            for (int k = 0; k < d[0] && ok; ++k) {
+                                const int q = d[1 + k];
+                                ok = q >= pl.K && q < n_prog && xcd_of[q] == xcd_of[pr] && last[q] < first[pr] && tiles_of[q] == d[7 + k];
+                            }
+                        }
+                        if (!ok) fail(CRAB_ERR_STATE, "clade work items: a table would be read before it is written");
+                    }
+                } else {
+                    // one launch per level: class-major (one class's matrices stay together), clades with most products first
+                    e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
+                    for (int l = 0; l < ct.n_levels; ++l) {
+                        crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+                        cl.list_off = (int)lists.size();
+                        cl.items_off = (int64_t)items.size();
+                        std::vector<int> order;
+                        for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
+                        std::stable_sort(order.begin(), order.end(),
+                                         [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
+                        // runs as long as the launch can afford while it still has ~3 items per resident workgroup
+                        int64_t level_tiles = 0;
+                        for (int j : order) level_tiles += ct.clades[j].tiles;
+                        const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, level_tiles * n_tab / (3 * slots)));
+                        std::vector<Item> its;
+                        for (int t = 0; t < n_tab; ++t)
+                            for (int j : order) {
+                                lists.push_back(pl.K + t * n_cl + j);
+                                items_of(t, j, run_len, its);
+                            }
+                        cl.n_entries = (int)lists.size() - cl.list_off;
+                        cl.n_items = (int64_t)its.size();
+                        // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that
+                        // share an L2 walk the same matrices); inside a chunk the longest items first -- the kernel hands a chunk's
+                        // items out in order to whichever of the XCD's workgroups asks next: the tail of the launch is a short item.
+                        double total = 0.0, acc = 0.0;
+                        for (const Item &it : its) total += it.w;
+                        int x = 1;
+                        cl.bounds[0] = 0;
+                        for (size_t i = 0; i < its.size() && x < 8; ++i) {
+                            acc += its[i].w;
+                            while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
+                        }
+                        while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
+                        cl.grid = prune_grid_size((int64_t)its.size(), e->device);
+                        for (int c8 = 0; c8 < 8; ++c8)
+                            std::stable_sort(its.begin() + cl.bounds[c8], its.begin() + cl.bounds[c8 + 1],
+                                             [](const Item &p, const Item &q) { return p.w > q.w; });
+                        for (const Item &it : its) items.push_back({it.prog, it.tile0, it.n});
+                    }
                 }
             }
             first_off = (int)lists.size();
@@ -2188,6 +2333,10 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             item_recs[i] = hdrs[items[i].prog];
             item_recs[i].prog = items[i].prog, item_recs[i].tile0 = items[i].tile0, item_recs[i].item_tiles = items[i].n;
         }
+        e->dev_n_prog = n_prog;
+        e->d_deps.ensure(dep_recs.size() + 16);
+        if (!dep_recs.empty())
+            HIP_CHECK(hipMemcpyAsync(e->d_deps.p, dep_recs.data(), dep_recs.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         e->d_items.ensure(item_recs.size() + 1);
         if (!item_recs.empty())
             HIP_CHECK(hipMemcpyAsync(e->d_items.p, item_recs.data(), item_recs.size() * sizeof(ProgHdr), hipMemcpyHostToDevice, e->stream));
@@ -2289,14 +2438,16 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     // Every launch of the pruning kernel hands its items out through eight counters of its own (PruneArgs::work_ctr;
     // CRAB_STATIC_ITEMS=1: items dealt round-robin instead, as in rounds 1-2).
     constexpr int MAX_PRUNE_LAUNCHES = 16;
-    static const bool dynamic_items = [] {
-        const char *sv = std::getenv("CRAB_STATIC_ITEMS");
-        return !(sv && sv[0] && sv[0] != '0');
-    }();
+    // Behind them in the same buffer, cleared with them: the fault flag and the per-program table counters of a merged clade launch.
+    constexpr int SYNC_AT = 8 * MAX_PRUNE_LAUNCHES;   // (PruneArgs::sync: the flag, 15 unused, the counters)
+    const bool dynamic_items = dynamic_items_enabled();
+    const bool merged = use_clades && !e->dev_clade_launches.empty() && e->dev_clade_launches[0].merged;
+    if (merged && !dynamic_items) fail(CRAB_ERR_ARG, "merged clade launch without dynamic work items");
     if (dynamic_items) {
-        e->d_work_ctr.ensure(8 * MAX_PRUNE_LAUNCHES);
+        const size_t n_ctr = (size_t)SYNC_AT + 16 + (merged ? (size_t)e->dev_n_prog : 0);
+        e->d_work_ctr.ensure(n_ctr);
         if ((int)e->dev_clade_launches.size() + 2 > MAX_PRUNE_LAUNCHES) fail(CRAB_ERR_ARG, "too many clade levels");
-        HIP_CHECK(hipMemsetAsync(e->d_work_ctr.p, 0, 8 * MAX_PRUNE_LAUNCHES * sizeof(int32_t), e->stream));
+        HIP_CHECK(hipMemsetAsync(e->d_work_ctr.p, 0, n_ctr * sizeof(int32_t), e->stream));
     }
     int launch_no = 0;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
@@ -2310,15 +2461,24 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
             pc.cls_list = e->d_cls.p + cl.list_off;
             pc.items = e->d_items.p + cl.items_off;
             pc.n_items = cl.n_items;
-            pc.codes_alt = e->d_codes_alt.p + l * (size_t)e->aln_rows * e->n_pat_pad;
-            pc.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[l] * e->n_pat_pad;   // (level 1 has no wide rows: never read)
+            pc.codes_alt = e->d_codes_alt.p;   // (a program's header names its level's slice; wide rows are numbered over all launches)
+            pc.idx32 = e->d_idx32.p;
+            if (cl.merged) {
+                pc.deps = e->d_deps.p;
+                pc.sync = e->d_work_ctr.p + SYNC_AT;
+            }
             std::copy(cl.bounds, cl.bounds + 9, pc.xcd_bounds);
             pc.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
             launch_prune(pc, cl.grid, e->stream);
         }
         // the main programs (among the first launch's) read the outermost clades' tables through the last block of wide rows
-        pa.idx32 = e->d_idx32.p + (size_t)e->clades.row_begin[e->clades.n_levels] * e->n_pat_pad;
+        pa.idx32 = e->d_idx32.p;
         pa.n_code_rows = e->aln_rows;
+        if (merged) {   // an XCD that ran no workgroup, a workgroup that gave up waiting: NaN instead of stale tables
+            pa.sync = e->d_work_ctr.p + SYNC_AT;
+            pa.expect = e->d_deps.p + (size_t)e->dev_n_prog * 16;
+            pa.n_expect = e->dev_n_prog;
+        }
     }
     pa.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
     launch_prune(pa, grid, e->stream);
@@ -2330,6 +2490,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         launch_prune(pa, grid_second, e->stream);
     }
     HIP_CHECK(hipEventRecord(e->ev_k1, e->stream));
+    if (merged && std::getenv("CRAB_DEBUG_SYNC")) {
+        int32_t h[16];
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(h, e->d_work_ctr.p + SYNC_AT, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[crab sync] flag %d: %d workgroup(s) gave up waiting; one of them: block %d on XCC %d\n", h[0], h[1], h[2] >> 8, h[2] & 255);
+    }
 
     e->h_out.ensure(G + (site_lnl ? (size_t)e->n_pat_pad : 0) + (pl.by_class ? (size_t)e->n_pat * pl.K : 0) +
                     (pl.beb ? (size_t)2 * pl.beb->G + (size_t)e->n_pat * pl.beb->n_mix : 0) +
@@ -3261,7 +3427,7 @@ int crab_compile_clade_tables(int n_nodes, const int32_t *node_ids, const int32_
             if (index_out) {   // per pattern (consumer: the main program) or per distinct sub-pattern of the consuming clade
                 const int launch = cl.parent < 0 ? ct.n_levels : ct.clades[cl.parent].level - 1;
                 const int64_t n = cl.parent < 0 ? n_patterns : ct.clades[cl.parent].U;
-                const uint32_t *row = idx.data() + (size_t)(ct.row_begin[launch] + cl.row) * npp;
+                const uint32_t *row = idx.data() + (size_t)cl.row * npp;
                 for (int64_t p = 0; p < n; ++p) index_out[p] = row[p];
             }
             if (sub_codes_out) {   // [n_leaves][U]: the codes of the clade's distinct sub-patterns on its own rows, n_states elsewhere

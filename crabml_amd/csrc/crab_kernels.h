@@ -107,7 +107,9 @@ struct alignas(16) ProgHdr {
     int32_t first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row;   // as in PruneArgs
     int32_t save_cls;  // class index inside the save area (the base vector's class with the same rate matrices)
     int32_t no_root;   // 1: a tree part -- the program ends by saving its tile (OP_LOAD with F_SAVE), no site likelihood is written
-    int32_t alt_codes; // 1: a clade program -- its leaf rows are read from PruneArgs::codes_alt (the clade's distinct sub-patterns)
+    int32_t alt_codes; // bit 0: a clade program -- its leaf rows are read from PruneArgs::codes_alt (the clade's distinct sub-patterns),
+                       // in the slice of level alt_codes >> 2 (0 = innermost); bit 1: the program gathers from tables written in
+                       // the SAME launch and waits for them first (PruneArgs::deps)
     int32_t first_gemm_mat, first_leaf_mat;   // matrices of ops first_gemm_op / first_leaf_op (-1 none): the item's prologue stages
                                               // the operand image and requests the columns without reading the ops first
     int32_t second_leaf_mat;   // >= 0: the program opens with two leaf edges of one node and this is the second one's matrix -- the
@@ -181,17 +183,29 @@ struct PruneArgs {
     const ProgHdr *items;     // [n_items] work items (ProgHdr::prog, tile0, item_tiles), or nullptr: the programs of cls_list in
                               // order, every tile, one tile per item
     int64_t n_items;
-    const uint8_t *codes_alt; // [n_rows][n_pat_pad] like codes
-    const uint32_t *idx32;    // [n_clades][n_pat_pad]
+    const uint8_t *codes_alt; // [n_levels][n_code_rows][n_pat_pad] like codes, one slice per nesting level
+    const uint32_t *idx32;    // [wide rows][n_pat_pad]
     int32_t n_code_rows;      // rows of `codes`; 0 = no wide rows in this launch
     int32_t *work_ctr;        // [8], zero before the launch: XCD x's workgroups take the items of its chunk in order, one at a
                               // time, whoever asks next (see prune_body); nullptr: a chunk's items are dealt round-robin
+    // One launch for the clade programs of all levels (the engine's default): a program whose header has alt_codes bit 1 waits,
+    // before its first gather, until every table it reads is complete.  A table and its counter are written and read by
+    // workgroups of ONE XCD only: the XCDs' L2s are not coherent with each other inside a launch.  The host keeps a clade and
+    // everything nested in it in one chunk of the item list, and with `deps` chunk x is handed out to the workgroups whose
+    // hardware XCC id is x, wherever the device put them.
+    const int32_t *deps;      // per program 16 ints [n, program x 6, tiles needed x 6, 0 0 0]; nullptr: not a merged clade launch
+    int32_t *sync;            // zero before the evaluation.  sync[0]: set by a workgroup that gave up waiting (sync[1], [2]: see
+                              // raise_fault); sync[16 + p]: the tiles of program p whose table stores have reached the L2
+    const int32_t *expect;    // a launch that reads those tables: expect[p] = tiles program p has announced if all went well; the
+    int32_t n_expect;         // launch writes NaN site likelihoods if a counter differs or sync[0] is set.  nullptr: no check
 #ifdef CRAB_PROF
     unsigned long long *prof; // diagnostic builds: per-wave phase counters (set by launch_prune), or nullptr
 #endif
 };
 // Stack slots the configured pruning kernel keeps in registers (the schedule must not park columns in the landing
 // tile of a product that pops a deeper, global-memory slot), and whether it has a prefetch tile at all.
+// Whether the device shows all eight XCDs (not a partition of the card): a merged clade launch has one chunk per XCD.
+bool prune_device_has_all_xcds(int device);
 int prune_reg_stack_slots();
 bool prune_has_prefetch();
 // Whether the configured kernel executes OP_LOAD / F_SAVE / F_POP_SAVED (the 64-pattern kernel does).

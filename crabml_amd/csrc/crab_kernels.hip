@@ -1272,6 +1272,47 @@ __device__ __forceinline__ void root_sum(const PruneArgs &a, const int (&eX)[NT]
     }
 }
 
+// Merged clade launch: thread 0 of a workgroup waits until the programs listed in `prog`'s dependency record have announced
+// all their tiles.  The counters are read with returning atomics (they execute in the XCD's L2, where the announcing
+// workgroups -- same XCD, by the host's construction -- added to them after their table stores were acknowledged), then the
+// CU's vector L1 is invalidated so that no gather of this item can hit a line from before.  The wait is bounded (a quarter
+// of a million polls, far beyond any launch): whoever gives up raises PruneArgs::fault and the evaluation returns NaN
+// rather than hanging the device.  The address is in VGPRs: nothing here reads an SGPR written by a VALU instruction.
+constexpr int XCC_ID_REG = 63508;   // s_getreg operand: hardware register 20 (XCC_ID), 32 bits from bit 0
+// (sync[1]: how many gave up; sync[2]: one of them, block << 8 | XCC.  CRAB_DEBUG_SYNC=1 prints them.)
+__device__ __forceinline__ void raise_fault(const PruneArgs &a)
+{
+    __builtin_nontemporal_store(1, a.sync);
+    atomicAdd(a.sync + 1, 1);
+    __builtin_nontemporal_store((int)(blockIdx.x << 8 | (__builtin_amdgcn_s_getreg(XCC_ID_REG) & 15u)), a.sync + 2);
+}
+__device__ __forceinline__ void wait_for_tables(const PruneArgs &a, int prog)
+{
+    if (threadIdx.x == 0) {
+        const int32_t *d = a.deps + (size_t)prog * 16;
+        const int n = d[0] < 6 ? d[0] : 6;
+        for (int k = 0; k < n; ++k) {
+            int32_t *ctr = a.sync + 16 + d[1 + k];
+            const int need = d[7 + k];
+            int got = 0;
+            for (int spin = 0; spin < (1 << 18); ++spin) {
+                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(ctr), "v"(0) : "memory");
+                if (got >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (got < need) raise_fault(a);
+        }
+        asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+__device__ __forceinline__ void announce_tiles(const PruneArgs &a, int prog, int tiles)
+{
+    if (threadIdx.x == 0) {
+        int32_t *ctr = a.sync + 16 + prog;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(ctr), "v"(tiles) : "memory");
+    }
+}
+
 // One workgroup = 4 waves = 64*NT patterns of one site class; each wave walks the whole tree program for its 16*NT
 // patterns with two register tiles (see walk()).  The program is per class (matrix indices resolved on the host),
 // so the only dependent global reads on the walk are the leaf-edge column gathers.
@@ -1298,7 +1339,10 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #ifdef CRAB_CLOCK
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int xcd = blockIdx.x % N_XCD, xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
+    // (a merged clade launch hands out XCD x's chunk to the workgroups that really run on XCD x: which XCD the device deals
+    // workgroup b to depends on what was launched before -- measured: workgroup 0 follows where the previous launch's last one went)
+    const int xcd = a.deps ? (int)(__builtin_amdgcn_s_getreg(XCC_ID_REG) & 7u) : (int)(blockIdx.x % N_XCD);
+    const int xj = blockIdx.x / N_XCD, per_xcd = gridDim.x / N_XCD;
     const long long chunk_lo = a.cls_list ? a.xcd_bounds[xcd] : n_work * xcd / N_XCD;
     const long long chunk_hi = a.cls_list ? a.xcd_bounds[xcd + 1] : n_work * (xcd + 1) / N_XCD;
     // Work distribution.  With work_ctr: the items of an XCD's chunk are handed out in order, one at a time, to whichever of
@@ -1326,6 +1370,15 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(number) : "v"(slot_addr) : "memory");
         return __builtin_amdgcn_readfirstlane(number);
     };
+    // A launch that reads the tables of a merged clade launch checks first that they are all there (every wave for itself: the
+    // counters and the flag were written back when that kernel ended): an XCD whose chunk found no workgroup, or a workgroup
+    // that gave up waiting, must show as NaN and not as a plausible number.
+    bool broken = false;
+    if (a.expect) {
+        int bad = lane == 0 ? a.sync[0] : 0;
+        for (int p = lane; p < a.n_expect; p += 64) bad |= a.sync[16 + p] ^ a.expect[p];
+        broken = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+    }
     if (dynamic) post_next_number(mbox);
     long long taken = 0;   // (an exit every wave reaches whatever the mailbox holds: never more items than the chunk has)
     long long wi = chunk_lo + xj - per_xcd;
@@ -1363,6 +1416,10 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         }
         const long long tile = item.tile;
         const int cls = item.cls;
+        if (a.deps && (item.h.alt_codes & 2)) {   // (the header is wave-uniform: every wave takes the same side)
+            wait_for_tables(a, cls);
+            __syncthreads();
+        }
         int n_ops, first_gemm_op, first_leaf_row, first_leaf_op, second_leaf_row, third_leaf_row, save_cls, no_root, alt_codes;
         {
             const ProgHdr &h = item.h;
@@ -1380,7 +1437,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         w.ops = a.ops + (size_t)cls * a.n_ops_pad;
         w.ip = 0;
         w.buf = 0;
-        w.codes = alt_codes ? a.codes_alt : a.codes;
+        w.codes = (alt_codes & 1) ? a.codes_alt + (size_t)(alt_codes >> 2) * (size_t)a.n_code_rows * (size_t)a.n_pat_pad : a.codes;
         w.pat = pat0;
         w.table_off = ((size_t)tile * 4 + wave) * 8192;
         w.gather0 = (const char *)(a.P + P_IMAGE);
@@ -1487,6 +1544,14 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             }
         }
     item_done:;
+        if (a.deps) {   // a clade program's table tiles: announced once every wave has seen its stores acknowledged
+            r_wait_vm0();
+            __syncthreads();
+            announce_tiles(a, __builtin_amdgcn_readfirstlane(cls), item_tiles);
+        } else if (broken && !no_root) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a.out_f[out_row + w.pat + nt * 16] = __builtin_nan("");
+        }
 #ifdef CRAB_PROF
         PROF_T(0)
         prof_acc = w.prof_acc;
@@ -1570,6 +1635,11 @@ int prune_configure_device()
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(prune_kernel_nt2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds_bytes());
     if (err == hipSuccess) (void)blocks_per_cu();
     return (int)err;
+}
+bool prune_device_has_all_xcds(int device)
+{
+    int n_xcc = 0;
+    return hipDeviceGetAttribute(&n_xcc, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && n_xcc == N_XCD;
 }
 int prune_tile_width() { return 64 * chosen_nt(); }
 int prune_reg_stack_slots() { return chosen_nt() == 1 ? Plan<1>::NSTK : Plan<2>::NSTK; }

@@ -24,4 +24,4 @@ with Engine(0) as eng:
         lnL = ev(); a, b, c = eng.last_timing(); dev.append(a); pr.append(b); eg.append(c)
     dt = (time.time() - t) / n
     dense, gather = eng.last_work()
-    print(f"{model} {n_taxa}x{n_sites} NT={os.environ.get('CRAB_NT','-')} BPC={os.environ.get('CRAB_BLOCKS_PER_CU','-')}: lnL={lnL:.6f} wall={dt*1e3:.3f} ms device={np.median(dev):.3f} prune={np.median(pr):.3f} eigen={np.median(eg):.3f} ms; {dense*7442/np.median(pr)/1e9:.2f} TFLOP/s", flush=True)
+    print(f"{model} {n_taxa}x{n_sites} NT={os.environ.get('CRAB_NT','-')} BPC={os.environ.get('CRAB_BLOCKS_PER_CU','-')}: lnL={lnL!r} wall={dt*1e3:.3f} ms device={np.median(dev):.3f} prune={np.median(pr):.3f} eigen={np.median(eg):.3f} ms; {dense*7442/np.median(pr)/1e9:.2f} TFLOP/s", flush=True)
