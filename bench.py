@@ -356,7 +356,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         updates_per_eval = world * N_SITES * n_branches * K           # reference units: every site, every branch, every class
         # With clade tables (subtree site repeats) a step launches the pruning kernel several times -- clade programs over the
-        # clades' distinct sub-patterns, one launch per nesting level, then the main programs -- and executes fewer products than
+        # clades' distinct sub-patterns in one launch, then the main programs -- and executes fewer products than
         # one per (pattern, internal branch, class).  The roofline counts what is EXECUTED, per launch, against the mean launch duration (what rocprofv3's kernel
         # stats average); the nominal count of a whole walk stands beside it.
         kernel_ms_step = float(np.mean(prune_ms))

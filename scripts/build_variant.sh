@@ -8,5 +8,5 @@ D=build_variants/$NAME
 rm -rf $D; mkdir -p $D/crabml_amd
 cp crabml_amd/*.py $D/crabml_amd/
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xarch_host -mavx2 -Xarch_host -mfma -Iinclude $FLAGS -o $D/crabml_amd/libcrabml_amd.so \
-    crabml_amd/csrc/crab_engine.cpp crabml_amd/csrc/crab_eigen.cpp crabml_amd/csrc/crab_quantiles.cpp crabml_amd/csrc/crab_kernels.hip crabml_amd/csrc/crab_noalloc.hip
+    crabml_amd/csrc/crab_engine.cpp crabml_amd/csrc/crab_programs.cpp crabml_amd/csrc/crab_workplan.cpp crabml_amd/csrc/crab_alignment.cpp crabml_amd/csrc/crab_models.cpp crabml_amd/csrc/crab_oneshot.cpp crabml_amd/csrc/crab_eigen.cpp crabml_amd/csrc/crab_quantiles.cpp crabml_amd/csrc/crab_kernels.hip crabml_amd/csrc/crab_noalloc.hip
 echo "built $D [$FLAGS]"
