@@ -391,7 +391,8 @@ def main():
                          "executed_dense_updates_per_step": dense, "whole_walk_dense_updates_per_step": nominal_dense,
                          "clade_tables": {"clades": n_clades, "distinct_sub_patterns": sub_patterns,
                                           "note": "clades of <= 64 leaves are walked once per distinct sub-pattern, inner clades first (one "
-                                                  "launch per nesting level), the main programs gather their messages (last launch); "
+                                                  "launch: a program waits for the tables it gathers from), the main programs gather "
+                                                  "their messages (second launch); "
                                                   "results bit-identical to whole walks (tests/test_clade_tables.py); "
                                                   "CRAB_NO_CLADE_TABLES=1 restores whole walks"},
                          "reference_algorithm_equivalent": {
