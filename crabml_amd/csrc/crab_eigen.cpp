@@ -219,7 +219,8 @@ static void reorthogonalise(int n, const double *zt, double *v)
 
 bool symmetric_eigen(int n, double *a, double *d)
 {
-    std::vector<double> e(n);
+    thread_local std::vector<double> e, zt;
+    e.assign(n, 0.0);
     for (int i = 0; i < n; ++i)  // symmetrise from the lower triangle
         for (int j = i + 1; j < n; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i];
     tridiagonalise(n, a, d, e.data());
@@ -230,7 +231,7 @@ bool symmetric_eigen(int n, double *a, double *d)
     transpose();
     const bool ok = ql_implicit(n, d, e.data(), a);
     if (ok) {
-        std::vector<double> zt(a, a + (size_t)n * n);
+        zt.assign(a, a + (size_t)n * n);
         reorthogonalise(n, zt.data(), a);
     } else {
         transpose();
@@ -262,16 +263,36 @@ bool spectral_decompose_plain(int n, const double *Q, const double *pi, double *
 
 bool spectral_decompose(int n, const double *Q, const double *pi, double *out)
 {
-    std::vector<double> U((size_t)n * n), Ui((size_t)n * n), lam(n);
-    if (!spectral_decompose_plain(n, Q, pi, U.data(), lam.data(), Ui.data())) return false;
-    std::memset(out, 0, sizeof(double) * EIG_STRIDE);
-    for (int k = 0; k < n; ++k) {
-        for (int i = 0; i < n; ++i) {
-            out[EIG_UT + k * NS + i] = U[(size_t)i * n + k];
-            out[EIG_UINV + k * NS + i] = Ui[(size_t)k * n + i];
-        }
-        out[EIG_LAM + k] = lam[k];
+    // (the same arithmetic as spectral_decompose_plain, written straight into the packed layout from per-thread scratch: the
+    // allocations, the zero fill and the strided repacking were a tenth of a decomposition)
+    if (n < 1 || n > NS) return false;
+    thread_local std::vector<double> S, lam, sq, isq;
+    S.resize((size_t)n * n), lam.resize(n), sq.resize(n), isq.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (!(pi[i] > 0.0)) return false;
+        sq[i] = std::sqrt(pi[i]);
+        isq[i] = 1.0 / sq[i];
     }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = sq[i] * Q[(size_t)i * n + j] * isq[j];
+    if (!symmetric_eigen(n, S.data(), lam.data())) return false;
+    for (int k = 0; k < n; ++k)
+        if (!std::isfinite(lam[k])) return false;
+    for (int i = 0; i < n; ++i) {   // S[i][k]: component i of eigenvector k
+        const double *row = S.data() + (size_t)i * n;
+        const double a = isq[i], b = sq[i];
+        for (int k = 0; k < n; ++k) {
+            out[EIG_UT + k * NS + i] = a * row[k];
+            out[EIG_UINV + k * NS + i] = row[k] * b;
+        }
+    }
+    for (int k = 0; k < NS; ++k) {   // zero padding: rows n .. NS-1 whole, columns n .. NS-1 of the others
+        const int from = k < n ? n : 0;
+        std::memset(out + EIG_UT + k * NS + from, 0, sizeof(double) * (NS - from));
+        std::memset(out + EIG_UINV + k * NS + from, 0, sizeof(double) * (NS - from));
+    }
+    std::memcpy(out + EIG_LAM, lam.data(), sizeof(double) * n);
+    std::memset(out + EIG_LAM + n, 0, sizeof(double) * (EIG_STRIDE - EIG_LAM - n));
     return true;
 }
 
