@@ -142,3 +142,42 @@ def test_batches_and_shards(gpu_engine_cls):
     finally:
         eng.close()
     assert n_cl > 0 and multi == multi_off and abs(multi - one) < 1e-7
+
+
+@pytest.mark.parametrize("model,taxa,sites,seed", [("M8", 100, 10000, 2), ("ModelA", 120, 2500, 6), ("free-ratio", 60, 3000, 4)])
+def test_one_clade_launch_against_one_per_level(gpu_engine_cls, monkeypatch, model, taxa, sites, seed):
+    """All nesting levels in one launch (work items wait for the tables they gather from) give the bits of one launch per
+    level (CRAB_CLADE_LEVEL_LAUNCHES=1, round 2's scheme), for single and batched evaluations, and of whole walks."""
+    from crabml_amd import synth
+    case = synth.make_case(model, taxa, sites, seed=seed)
+
+    def evaluate(eng):
+        if model == "ModelA":
+            return eng.branch_site(case.Q3, *case.qfactors, case.omega0, case.omega2, case.site_class_freqs, case.pi, case.branch_lengths,
+                                   case.branch_labels, return_sites=True)
+        if model == "free-ratio":
+            return eng.branch(case.Q_per_node, case.pi, case.branch_lengths, return_sites=True)
+        return eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths, return_sites=True)
+
+    with _engine(gpu_engine_cls, case) as eng:
+        merged, site_merged = evaluate(eng)
+        n_merged = eng.last_prune_launches()
+        n_cl, _ = eng.last_clade_tables()
+        again, _ = evaluate(eng)
+        if model == "M8":   # a batch: every vector gets tables of its own, all in the one launch
+            t2 = np.stack([case.branch_lengths, case.branch_lengths * 1.01, case.branch_lengths * 0.99])
+            batch_merged = eng.site_classes_batch(np.stack([case.Q] * 3), np.stack([case.proportions] * 3), case.pi, t2)
+    monkeypatch.setenv("CRAB_CLADE_LEVEL_LAUNCHES", "1")
+    with _engine(gpu_engine_cls, case) as eng:
+        levels, site_levels = evaluate(eng)
+        n_levels = eng.last_prune_launches()
+        if model == "M8":
+            batch_levels = eng.site_classes_batch(np.stack([case.Q] * 3), np.stack([case.proportions] * 3), case.pi, t2)
+        eng.set_clade_tables(False)
+        whole, site_whole = evaluate(eng)
+    print(f"{model} {taxa} x {sites}: {n_cl} clades, launches {n_merged} merged / {n_levels} per level")
+    assert n_cl > 0 and n_merged == 2 and n_levels >= n_merged
+    assert merged == levels == whole == again
+    assert np.array_equal(site_merged, site_levels) and np.array_equal(site_merged, site_whole)
+    if model == "M8":
+        assert np.array_equal(batch_merged, batch_levels) and batch_merged[0] == merged
