@@ -450,8 +450,12 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         pa.n_code_rows = e->aln_rows;
         if (merged) {   // an XCD that ran no workgroup, a workgroup that gave up waiting: NaN instead of stale tables
             pa.sync = e->d_work_ctr.p + SYNC_AT;
-            pa.expect = e->d_deps.p + (size_t)e->dev_n_prog * 16;
-            pa.n_expect = e->dev_n_prog;
+            pa.expect_tiles = e->dev_clade_tiles;
+            e->h_sync_flag.ensure(1);
+            e->h_sync_flag.p[0] = 0;
+            pa.host_flag = e->h_sync_flag.dev;
+            if (const char *sv = std::getenv("CRAB_DEBUG_SYNC"))   // "2": pretend a tile went missing (the tests' way to see the NaN)
+                if (sv[0] == '2') pa.expect_tiles += 1;
         }
     }
     pa.work_ctr = dynamic_items ? e->d_work_ctr.p + 8 * launch_no++ : nullptr;
@@ -587,6 +591,9 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     HIP_CHECK(hipStreamSynchronize(e->stream));
     HIP_CHECK(hipGetLastError());
+    if (merged && e->h_sync_flag.p && e->h_sync_flag.p[0] != 0)
+        fail(CRAB_ERR_DEVICE, "clade tables incomplete: a work item of the merged clade launch gave up waiting, or one of the device's "
+                              "XCDs ran no workgroup (CRAB_CLADE_LEVEL_LAUNCHES=1 runs one launch per nesting level instead)");
     if (device_eigen && e->h_eig_status.p[0] != 0) {   // forget what kernel 0 left in the new slots
         for (int sl : new_slots) pool.drop(sl);
         fail(CRAB_ERR_EIGEN, "Eigendecomposition failed: the device solver did not converge in 24 sweeps");

@@ -517,6 +517,7 @@ struct crab_engine : TreeProgram {
     DevBuf<double> d_weights, d_small, d_P, d_stack, d_f, d_patlnl, d_partials, d_lnL, d_byclass;
     DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_work_ctr, d_deps;
     int dev_n_prog = 0;
+    int32_t dev_clade_tiles = 0;        // tiles a merged clade launch announces in all
     DevBuf<ProgHdr> d_items;
     DevBuf<uint32_t> d_idx32;
     DevBuf<uint8_t> d_codes_alt;
@@ -528,6 +529,7 @@ struct crab_engine : TreeProgram {
     DevBuf<double> d_S;
     DevBuf<int32_t> d_eig_status;   // kernel 0's convergence flag
     PinBuf<int32_t> h_eig_status;
+    PinBuf<int32_t> h_sync_flag;    // set by the device when the tables of a merged clade launch turn out incomplete
     bool device_eigen = false;   // decompose on the device (kernel 0) instead of on the host: crab_set_eigensolver
 
     EigPool eig_pool;
@@ -557,7 +559,7 @@ struct crab_engine : TreeProgram {
         d_stack.release(); d_f.release(); d_patlnl.release(); d_partials.release();
         d_lnL.release(); d_byclass.release(); d_stack_e.release(); d_e.release(); d_cls.release(); d_hdr.release(); d_save.release(); d_items.release(); d_work_ctr.release(); d_deps.release(); d_idx32.release(); d_codes_alt.release();
         d_beb_cols.release(); d_beb_F.release(); d_beb_props.release(); d_beb_lnfx.release(); d_beb_w.release(); d_beb_post.release();
-        h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release(); d_eig_status.release(); h_eig_status.release();
+        h_eig.release(); h_small.release(); h_out.release(); h_S.release(); d_S.release(); d_eig_status.release(); h_eig_status.release(); h_sync_flag.release();
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
         if (ev_k0) (void)hipEventDestroy(ev_k0);

@@ -195,9 +195,13 @@ struct PruneArgs {
     // hardware XCC id is x, wherever the device put them.
     const int32_t *deps;      // per program 16 ints [n, program x 6, tiles needed x 6, 0 0 0]; nullptr: not a merged clade launch
     int32_t *sync;            // zero before the evaluation.  sync[0]: set by a workgroup that gave up waiting (sync[1], [2]: see
-                              // raise_fault); sync[16 + p]: the tiles of program p whose table stores have reached the L2
-    const int32_t *expect;    // a launch that reads those tables: expect[p] = tiles program p has announced if all went well; the
-    int32_t n_expect;         // launch writes NaN site likelihoods if a counter differs or sync[0] is set.  nullptr: no check
+                              // raise_fault); sync[4 + x]: the tiles the workgroups of XCD x have announced in all;
+                              // sync[16 + p]: the tiles of program p whose table stores have reached the L2
+    int32_t expect_tiles;     // > 0: this launch reads the tables of a merged clade launch that should have announced this many
+                              // tiles in all; it writes NaN site likelihoods if the sync[4 .. 11] add up to something else
+                              // or sync[0] is set
+    int32_t *host_flag;       // with expect_tiles: pinned host memory as the device addresses it; set to 1 when the check fails, so
+                              // that the host can return an error whatever the mixture's clamp makes of a NaN (nullptr: NaN only)
 #ifdef CRAB_PROF
     unsigned long long *prof; // diagnostic builds: per-wave phase counters (set by launch_prune), or nullptr
 #endif

@@ -1371,14 +1371,20 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         return __builtin_amdgcn_readfirstlane(number);
     };
     // A launch that reads the tables of a merged clade launch checks first that they are all there (every wave for itself: the
-    // counters and the flag were written back when that kernel ended): an XCD whose chunk found no workgroup, or a workgroup
-    // that gave up waiting, must show as NaN and not as a plausible number.
+    // per-XCD totals and the flag were written back when that kernel ended): an XCD whose chunk found no workgroup, or a
+    // workgroup that gave up waiting, must show as NaN and not as a plausible number.
     bool broken = false;
-    if (a.expect) {
-        int bad = lane == 0 ? a.sync[0] : 0;
-        for (int p = lane; p < a.n_expect; p += 64) bad |= a.sync[16 + p] ^ a.expect[p];
+    if (a.expect_tiles > 0) {
+        int bad = 0;
+        if (lane == 0) {
+            int sum = 0;
+            for (int x = 0; x < N_XCD; ++x) sum += a.sync[4 + x];
+            bad = (a.sync[0] != 0) | (sum != a.expect_tiles);
+        }
         broken = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+        if (broken && a.host_flag && threadIdx.x == 0) __builtin_nontemporal_store(1, a.host_flag);
     }
+    int announced = 0;   // tiles this workgroup has announced (merged clade launch): added to its XCD's total at the end
     if (dynamic) post_next_number(mbox);
     long long taken = 0;   // (an exit every wave reaches whatever the mailbox holds: never more items than the chunk has)
     long long wi = chunk_lo + xj - per_xcd;
@@ -1548,6 +1554,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             r_wait_vm0();
             __syncthreads();
             announce_tiles(a, __builtin_amdgcn_readfirstlane(cls), item_tiles);
+            announced += item_tiles;
         } else if (broken && !no_root) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) a.out_f[out_row + w.pat + nt * 16] = __builtin_nan("");
@@ -1556,6 +1563,10 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         PROF_T(0)
         prof_acc = w.prof_acc;
 #endif
+    }
+    if (a.deps && announced > 0 && threadIdx.x == 0) {
+        int32_t *total = a.sync + 4 + xcd;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(total), "v"(announced) : "memory");
     }
 #ifdef CRAB_PROF
     if (a.prof && lane < 2 * PROF_N) ((unsigned *)a.prof)[((size_t)blockIdx.x * 4 + wave) * (2 * PROF_N) + lane] = prof_acc;

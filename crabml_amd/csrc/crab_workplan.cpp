@@ -278,13 +278,12 @@ WorkSplit plan_device_work(crab_engine *e, const EvalPlan &pl, const std::vector
                     cl.n_items = cl.bounds[8];
                     cl.grid = prune_grid_size(cl.n_items, e->device);
                     cl.merged = true;
-                    // one record per program: [n, program x 6, tiles needed x 6, 0, 0, 0]; behind them, per program, the tiles it
-                    // announces in all (PruneArgs::expect)
-                    dep_recs.assign((size_t)n_prog * 17, 0);
+                    // one record per program: [n, program x 6, tiles needed x 6, 0, 0, 0]
+                    dep_recs.assign((size_t)n_prog * 16, 0);
+                    e->dev_clade_tiles = (int32_t)(all_tiles * n_tab);   // what the launch announces in all (PruneArgs::expect_tiles)
                     for (int t = 0; t < n_tab; ++t)
                         for (int j = 0; j < n_cl; ++j) {
                             int32_t *d = dep_recs.data() + (size_t)(pl.K + t * n_cl + j) * 16;
-                            dep_recs[(size_t)n_prog * 16 + pl.K + t * n_cl + j] = (int32_t)ct.clades[j].tiles;
                             for (int c2 = 0; c2 < n_cl; ++c2)
                                 if (ct.clades[c2].parent == j) {
                                     d[1 + d[0]] = pl.K + t * n_cl + c2;
