@@ -379,7 +379,22 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
         launch_eigen(d_eig_S, d_eig_slots, d_eig_sqrt_pi, pool.d, (int)todo.size(), n, e->d_eig_status.p, e->stream);
         HIP_CHECK(hipMemcpyAsync(e->h_eig_status.p, e->d_eig_status.p, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     }
-    launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, M, n, true, e->stream);
+    // Every launch of the pruning kernel hands its items out through eight counters of its own (PruneArgs::work_ctr;
+    // CRAB_STATIC_ITEMS=1: items dealt round-robin instead, as in rounds 1-2).  Behind them in the same buffer: the fault flag,
+    // the per-XCD totals and the per-program table counters of a merged clade launch.  All zero before the first pruning launch:
+    // kernel 1, which runs ahead of them on the stream, clears the buffer (a memset of 3 KB was two fill launches per step).
+    constexpr int MAX_PRUNE_LAUNCHES = 16;
+    constexpr int SYNC_AT = 8 * MAX_PRUNE_LAUNCHES;   // (PruneArgs::sync: the flag, the totals, the counters)
+    const bool dynamic_items = dynamic_items_enabled();
+    const bool merged = use_clades && !e->dev_clade_launches.empty() && e->dev_clade_launches[0].merged;
+    if (merged && !dynamic_items) fail(CRAB_ERR_ARG, "merged clade launch without dynamic work items");
+    size_t n_ctr = 0;
+    if (dynamic_items) {
+        n_ctr = (size_t)SYNC_AT + 16 + (merged ? (size_t)e->dev_n_prog : 0);
+        e->d_work_ctr.ensure(n_ctr);
+        if ((int)e->dev_clade_launches.size() + 2 > MAX_PRUNE_LAUNCHES) fail(CRAB_ERR_ARG, "too many clade levels");
+    }
+    launch_build_p(pool.d, d_eig_id, d_teff, e->d_P.p, M, n, true, e->stream, n_ctr ? e->d_work_ctr.p : nullptr, (int)n_ctr);
 
     PruneArgs pa{};
     pa.ops = e->d_ops.p;
@@ -409,20 +424,6 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     pa.third_leaf_row = e->third_leaf_row;
     pa.second_leaf_op = e->second_leaf_op;
     pa.fourth_leaf_row = e->fourth_leaf_row;
-    // Every launch of the pruning kernel hands its items out through eight counters of its own (PruneArgs::work_ctr;
-    // CRAB_STATIC_ITEMS=1: items dealt round-robin instead, as in rounds 1-2).
-    constexpr int MAX_PRUNE_LAUNCHES = 16;
-    // Behind them in the same buffer, cleared with them: the fault flag and the per-program table counters of a merged clade launch.
-    constexpr int SYNC_AT = 8 * MAX_PRUNE_LAUNCHES;   // (PruneArgs::sync: the flag, 15 unused, the counters)
-    const bool dynamic_items = dynamic_items_enabled();
-    const bool merged = use_clades && !e->dev_clade_launches.empty() && e->dev_clade_launches[0].merged;
-    if (merged && !dynamic_items) fail(CRAB_ERR_ARG, "merged clade launch without dynamic work items");
-    if (dynamic_items) {
-        const size_t n_ctr = (size_t)SYNC_AT + 16 + (merged ? (size_t)e->dev_n_prog : 0);
-        e->d_work_ctr.ensure(n_ctr);
-        if ((int)e->dev_clade_launches.size() + 2 > MAX_PRUNE_LAUNCHES) fail(CRAB_ERR_ARG, "too many clade levels");
-        HIP_CHECK(hipMemsetAsync(e->d_work_ctr.p, 0, n_ctr * sizeof(int32_t), e->stream));
-    }
     int launch_no = 0;
     HIP_CHECK(hipEventRecord(e->ev_k0, e->stream));
     if (use_clades) {     // one launch per level: the clade programs, over each clade's distinct sub-patterns

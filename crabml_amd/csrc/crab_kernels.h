@@ -136,7 +136,8 @@ inline int64_t dev_ops_padded(int64_t n_ops) { return ((n_ops + 63) / 64) * 64 +
 // matrix m is then left unwritten (nothing reads a leaf edge's operand image or an internal edge's gather image).
 constexpr int32_t BUILD_P_NO_GATHER = 1 << 29, BUILD_P_NO_OPERAND = 1 << 30;
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
-                    bool clamp_negative, hipStream_t stream);
+                    bool clamp_negative, hipStream_t stream, int32_t *zero = nullptr, int n_zero = 0);   // zero[0 .. n_zero): cleared
+                                                                                   // by the launch's last workgroup (the pruning launches' counters)
 
 // ---- kernel 0: batched spectral decomposition on the device  (replaces matrix.rs:31-75 where many matrices change per
 // call: free-ratio fits, gene scans; the host solver of crab_eigen.cpp stays the default) ----------------------------

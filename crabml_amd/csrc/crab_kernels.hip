@@ -51,8 +51,10 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // and at ~250 cycles per fp64 exp more work than the kernel's MFMAs).
 __global__ __launch_bounds__(256, 2) void build_p_kernel(const double *__restrict__ eig, const int32_t *__restrict__ eig_id,
                                                       const double *__restrict__ t_eff, double *__restrict__ P, int n_states,
-                                                      int clamp_negative, int M, int per_wg)
+                                                      int clamp_negative, int M, int per_wg, int32_t *__restrict__ zero, int n_zero)
 {
+    if (zero && blockIdx.x == gridDim.x - 1)
+        for (int z = threadIdx.x; z < n_zero; z += 256) zero[z] = 0;
     const int lane = threadIdx.x & 63;
     const int mt = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -136,15 +138,18 @@ __global__ __launch_bounds__(256, 2) void build_p_kernel(const double *__restric
 }
 
 void launch_build_p(const double *eig, const int32_t *eig_id, const double *t_eff, double *P, int M, int n_states,
-                    bool clamp_negative, hipStream_t stream)
+                    bool clamp_negative, hipStream_t stream, int32_t *zero, int n_zero)
 {
-    if (M <= 0) return;
+    if (M <= 0) {
+        if (zero && n_zero > 0) (void)hipMemsetAsync(zero, 0, (size_t)n_zero * sizeof(int32_t), stream);
+        return;
+    }
     // one round of workgroups (two fit a CU at this kernel's register count), each with a run of the matrix list
     int per_wg = (M + 511) / 512;
     static const int per_wg_env = std::getenv("CRAB_BUILD_P_PER_WG") ? std::atoi(std::getenv("CRAB_BUILD_P_PER_WG")) : 0;   // experiments
     if (per_wg_env > 0) per_wg = per_wg_env;
     const int grid = (M + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL(build_p_kernel, dim3(grid), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0, M, per_wg);
+    hipLaunchKernelGGL(build_p_kernel, dim3(grid), dim3(256), 0, stream, eig, eig_id, t_eff, P, n_states, clamp_negative ? 1 : 0, M, per_wg, zero, n_zero);
 }
 
 // =============================================================================================
