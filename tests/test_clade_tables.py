@@ -163,6 +163,7 @@ def test_one_clade_launch_against_one_per_level(gpu_engine_cls, monkeypatch, mod
         merged, site_merged = evaluate(eng)
         n_merged = eng.last_prune_launches()
         n_cl, _ = eng.last_clade_tables()
+        cut = eng.last_tree_parts() > 0      # an under-filled launch of main programs is cut into subtree programs + roots
         again, _ = evaluate(eng)
         if model == "M8":   # a batch: every vector gets tables of its own, all in the one launch
             t2 = np.stack([case.branch_lengths, case.branch_lengths * 1.01, case.branch_lengths * 0.99])
@@ -176,7 +177,7 @@ def test_one_clade_launch_against_one_per_level(gpu_engine_cls, monkeypatch, mod
         eng.set_clade_tables(False)
         whole, site_whole = evaluate(eng)
     print(f"{model} {taxa} x {sites}: {n_cl} clades, launches {n_merged} merged / {n_levels} per level")
-    assert n_cl > 0 and n_merged == 2 and n_levels >= n_merged
+    assert n_cl > 0 and n_merged == 2 + cut and n_levels >= n_merged
     assert merged == levels == whole == again
     assert np.array_equal(site_merged, site_levels) and np.array_equal(site_merged, site_whole)
     if model == "M8":
@@ -192,7 +193,7 @@ def test_missing_table_tiles_are_an_error(gpu_engine_cls, monkeypatch):
     case = synth.make_case("M8", 30, 2000, seed=11)
     with _engine(gpu_engine_cls, case) as eng:
         good = eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths)
-        assert np.isfinite(good) and eng.last_prune_launches() == 2
+        assert np.isfinite(good) and eng.last_prune_launches() == 2 + (eng.last_tree_parts() > 0)
         monkeypatch.setenv("CRAB_DEBUG_SYNC", "2")
         with pytest.raises(L.CrabError, match="clade tables incomplete") as err:
             eng.site_classes(case.Q, case.proportions, case.pi, case.branch_lengths)
