@@ -592,12 +592,21 @@ void run_plan(crab_engine *e, const EvalPlan &pl, const double *pi, double *lnL,
     }
     HIP_CHECK(hipStreamSynchronize(e->stream));
     HIP_CHECK(hipGetLastError());
-    if (merged && e->h_sync_flag.p && e->h_sync_flag.p[0] != 0)
-        fail(CRAB_ERR_DEVICE, "clade tables incomplete: a work item of the merged clade launch gave up waiting, or one of the device's "
-                              "XCDs ran no workgroup (CRAB_CLADE_LEVEL_LAUNCHES=1 runs one launch per nesting level instead)");
     if (device_eigen && e->h_eig_status.p[0] != 0) {   // forget what kernel 0 left in the new slots
         for (int sl : new_slots) pool.drop(sl);
         fail(CRAB_ERR_EIGEN, "Eigendecomposition failed: the device solver did not converge in 24 sweeps");
+    }
+    if (merged && e->h_sync_flag.p && e->h_sync_flag.p[0] != 0) {
+        // The merged clade launch left tables incomplete: a work item gave up waiting, or one of the device's XCDs ran no workgroup
+        // of the launch (nothing promises how a device deals workgroups to its XCDs).  Nothing of this evaluation is used: the
+        // engine goes back to one launch per nesting level, for good, and evaluates again (the decompositions are in the pool).
+        if (e->merged_clade_launch_off) fail(CRAB_ERR_DEVICE, "clade tables incomplete");
+        fprintf(stderr, "[crabml_amd] device %d: the one-launch schedule of the clade programs left tables incomplete; this engine "
+                        "uses one launch per nesting level from here on (CRAB_CLADE_LEVEL_LAUNCHES=1 does so from the start)\n", e->device);
+        e->merged_clade_launch_off = true;
+        e->dev_ops.clear();   // plan and upload the programs again
+        run_plan(e, pl, pi, lnL, site_lnl, by_class_out);
+        return;
     }
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev_begin, e->ev_end));

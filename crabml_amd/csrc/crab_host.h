@@ -518,6 +518,7 @@ struct crab_engine : TreeProgram {
     DevBuf<int32_t> d_stack_e, d_e, d_beb_cols, d_cls, d_work_ctr, d_deps;
     int dev_n_prog = 0;
     int32_t dev_clade_tiles = 0;        // tiles a merged clade launch announces in all
+    bool merged_clade_launch_off = false;   // a merged clade launch of this engine left tables incomplete once: level launches since
     DevBuf<ProgHdr> d_items;
     DevBuf<uint32_t> d_idx32;
     DevBuf<uint8_t> d_codes_alt;

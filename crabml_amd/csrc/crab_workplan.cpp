@@ -118,7 +118,7 @@ WorkSplit plan_device_work(crab_engine *e, const EvalPlan &pl, const std::vector
         std::vector<int32_t> dep_recs;              // merged clade launch: per program, the tables it waits for
         // CRAB_CLADE_LEVEL_LAUNCHES=1: one launch per nesting level, as in round 2.  The merged launch needs the dynamic hand-out
         // (an item is only ever held by a workgroup that is running) and a device that deals workgroups to XCDs by number.
-        const bool merged_clade_launch = !clade_level_launches_forced() && dynamic_items_enabled() && prune_device_has_all_xcds(e->device);
+        const bool merged_clade_launch = !clade_level_launches_forced() && !e->merged_clade_launch_off && dynamic_items_enabled() && prune_device_has_all_xcds(e->device);
         if (n_parts > 0) {
             const TreeParts &tp = e->tree_parts;
             for (int k = 0; k < pl.K; ++k) {
