@@ -3,6 +3,206 @@
 
 namespace crab_host {
 
+namespace {
+struct ItemRef {   // a work item of a clade launch: (program, first tile, tiles)
+    int32_t prog, tile0, n;
+};
+}  // namespace
+
+// The clade programs of one evaluation as launches of work items: ONE launch whose items wait for the tables they gather from
+// (merged_allowed, and no clade with more inner clades than a dependency record holds), or one launch per nesting level.
+// Appends to the program list and the item list, fills the dependency records and the waiting bit of the headers, and leaves
+// the launches in e->dev_clade_launches.  n_cl clades x n_tab tabled classes; clade (t, j) is program K + t * n_cl + j of n_prog.
+static void schedule_clade_launches(crab_engine *e, const CladeTables &ct, int K, int n_tab, int n_prog, bool merged_allowed,
+                                    std::vector<int32_t> &lists, std::vector<ItemRef> &items, std::vector<int32_t> &dep_recs,
+                                    std::vector<ProgHdr> &hdrs)
+{
+    const int n_cl = (int)ct.clades.size();
+    // Work items: runs of consecutive tiles of one (class, clade) -- a cyclic program pays its prologue (item -> header
+    // -> ops, codes -> columns -> operand image: a chain of dependent loads) once per item, later tiles start from what
+    // the previous tile's last product requested.
+    struct Item {
+        int32_t prog, tile0, n, level;
+        double w;
+    };
+    auto env_w = [](const char *name, double dflt) {
+        const char *sv = std::getenv(name);
+        return sv && sv[0] ? std::atof(sv) : dflt;
+    };
+    // predicted time of an item in products: a prologue, and per tile its products and a sixth of a product for the
+    // rest (fitted to per-workgroup busy times, scripts/gpu_prof_phases.sh with -DCRAB_CLOCK)
+    const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
+    const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device);
+    auto items_of = [&](int t, int j, int64_t run_len, std::vector<Item> &out) {
+        const ProgInfo &in = ct.clades[j].prog.info;
+        const int64_t tiles = ct.clades[j].tiles;
+        const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
+        for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
+            const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
+            out.push_back({(int32_t)(K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo), ct.clades[j].level,
+                           w_item + (double)(hi - lo) * (in.n_gemm + w_tile)});
+        }
+    };
+    int64_t run_env = 0;
+    if (const char *sv = std::getenv("CRAB_CLADE_ITEM_TILES")) run_env = std::max(1, std::min(64, std::atoi(sv)));
+    for (int t = 0; t < n_tab; ++t)
+        for (int j = 0; j < n_cl; ++j) e->dev_gemm_extra += (int64_t)ct.clades[j].prog.info.n_gemm * ct.clades[j].tiles * prune_tile_width();
+    // A clade with more inner clades than a dependency record holds (6) cannot wait for them inside a launch.
+    bool merge = merged_allowed;
+    for (int j = 0; j < n_cl && merge; ++j) {
+        int inner = 0;
+        for (int c2 = 0; c2 < n_cl; ++c2) inner += ct.clades[c2].parent == j;
+        merge = inner <= 6;
+    }
+    dep_recs.clear();
+    if (merge) {
+        // ONE launch for the clade programs of all levels.  A unit = one class's copy of an outermost clade with every
+        // clade nested inside it: tables are written and read inside a unit only.  Units are dealt to the XCDs by
+        // predicted work (largest first, each to the XCD with the least so far), so a table and the counter that
+        // announces it stay in one XCD's L2 -- nothing in the launch depends on coherence between XCDs.  An XCD's
+        // items are ordered by level, then longest first; the kernel hands them out in that order and an item whose
+        // program gathers from inner clades' tables waits for their counters (PruneArgs::deps, ::done): every item it
+        // waits for sits earlier in the same queue, and items of level 1 wait for nothing, so by induction over the
+        // levels every wait ends.
+        int64_t all_tiles = 0;
+        for (int j = 0; j < n_cl; ++j) all_tiles += ct.clades[j].tiles;
+        const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, all_tiles * n_tab / (6 * slots)));
+        std::vector<int> outer_of(n_cl);
+        for (int j = 0; j < n_cl; ++j) {
+            int r = j;
+            while (ct.clades[r].parent >= 0) r = ct.clades[r].parent;
+            outer_of[j] = r;
+        }
+        struct Unit {
+            std::vector<Item> its;
+            double w = 0.0;
+        };
+        std::vector<Unit> units;
+        std::vector<int> unit_of(n_cl, -1);
+        for (int t = 0; t < n_tab; ++t) {
+            std::fill(unit_of.begin(), unit_of.end(), -1);
+            for (int j = 0; j < n_cl; ++j) {
+                int &u = unit_of[outer_of[j]];
+                if (u < 0) {
+                    u = (int)units.size();
+                    units.emplace_back();
+                }
+                const size_t before = units[u].its.size();
+                items_of(t, j, run_len, units[u].its);
+                for (size_t i = before; i < units[u].its.size(); ++i) units[u].w += units[u].its[i].w;
+            }
+        }
+        std::vector<int> by_w(units.size());
+        for (size_t u = 0; u < units.size(); ++u) by_w[u] = (int)u;
+        std::stable_sort(by_w.begin(), by_w.end(), [&](int p, int q) { return units[p].w > units[q].w; });
+        std::vector<std::vector<Item>> of_xcd(8);
+        double load[8] = {0};
+        for (int u : by_w) {
+            const int x = (int)(std::min_element(load, load + 8) - load);
+            load[x] += units[u].w;
+            of_xcd[x].insert(of_xcd[x].end(), units[u].its.begin(), units[u].its.end());
+        }
+        e->dev_clade_launches.assign(1, crab_engine::CladeLaunch{});
+        crab_engine::CladeLaunch &cl = e->dev_clade_launches[0];
+        cl.list_off = (int)lists.size();
+        cl.items_off = (int64_t)items.size();
+        for (int t = 0; t < n_tab; ++t)
+            for (int j = 0; j < n_cl; ++j) lists.push_back(K + t * n_cl + j);
+        cl.n_entries = (int)lists.size() - cl.list_off;
+        cl.bounds[0] = 0;
+        for (int x = 0; x < 8; ++x) {
+            std::stable_sort(of_xcd[x].begin(), of_xcd[x].end(),
+                             [](const Item &p, const Item &q) { return p.level != q.level ? p.level < q.level : p.w > q.w; });
+            for (const Item &it : of_xcd[x]) items.push_back({it.prog, it.tile0, it.n});
+            cl.bounds[x + 1] = cl.bounds[x] + (int64_t)of_xcd[x].size();
+        }
+        cl.n_items = cl.bounds[8];
+        cl.grid = prune_grid_size(cl.n_items, e->device);
+        cl.merged = true;
+        // one record per program: [n, program x 6, tiles needed x 6, 0, 0, 0]
+        dep_recs.assign((size_t)n_prog * 16, 0);
+        e->dev_clade_tiles = (int32_t)(all_tiles * n_tab);   // what the launch announces in all (PruneArgs::expect_tiles)
+        for (int t = 0; t < n_tab; ++t)
+            for (int j = 0; j < n_cl; ++j) {
+                int32_t *d = dep_recs.data() + (size_t)(K + t * n_cl + j) * 16;
+                for (int c2 = 0; c2 < n_cl; ++c2)
+                    if (ct.clades[c2].parent == j) {
+                        d[1 + d[0]] = K + t * n_cl + c2;
+                        d[7 + d[0]] = (int32_t)ct.clades[c2].tiles;
+                        ++d[0];
+                    }
+                if (d[0] > 0) hdrs[K + t * n_cl + j].alt_codes |= 2;
+            }
+        // What the kernel's waits rely on, checked here rather than found out on the device: every program's items sit
+        // in one XCD's chunk, after all items of the programs it waits for, whose tiles add up to what it waits for.
+        {
+            std::vector<int64_t> first(n_prog, -1), last(n_prog, -1), tiles_of(n_prog, 0);
+            std::vector<int> xcd_of(n_prog, -1);
+            bool ok = true;
+            for (int x = 0; x < 8; ++x)
+                for (int64_t i = cl.bounds[x]; i < cl.bounds[x + 1]; ++i) {
+                    const ItemRef &it = items[(size_t)(cl.items_off + i)];
+                    ok = ok && it.prog >= K && it.prog < n_prog && (xcd_of[it.prog] < 0 || xcd_of[it.prog] == x);
+                    if (!ok) break;
+                    xcd_of[it.prog] = x;
+                    if (first[it.prog] < 0) first[it.prog] = i;
+                    last[it.prog] = i;
+                    tiles_of[it.prog] += it.n;
+                }
+            for (int pr = K; pr < n_prog && ok; ++pr) {
+                const int32_t *d = dep_recs.data() + (size_t)pr * 16;
+                ok = first[pr] >= 0 && d[0] >= 0 && d[0] <= 6 && tiles_of[pr] == ct.clades[(pr - K) % n_cl].tiles;
+                for (int k = 0; k < d[0] && ok; ++k) {
+                    const int q = d[1 + k];
+                    ok = q >= K && q < n_prog && xcd_of[q] == xcd_of[pr] && last[q] < first[pr] && tiles_of[q] == d[7 + k];
+                }
+            }
+            if (!ok) fail(CRAB_ERR_STATE, "clade work items: a table would be read before it is written");
+        }
+    } else {
+        // one launch per level: class-major (one class's matrices stay together), clades with most products first
+        e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
+        for (int l = 0; l < ct.n_levels; ++l) {
+            crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
+            cl.list_off = (int)lists.size();
+            cl.items_off = (int64_t)items.size();
+            std::vector<int> order;
+            for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
+            // runs as long as the launch can afford while it still has ~3 items per resident workgroup
+            int64_t level_tiles = 0;
+            for (int j : order) level_tiles += ct.clades[j].tiles;
+            const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, level_tiles * n_tab / (3 * slots)));
+            std::vector<Item> its;
+            for (int t = 0; t < n_tab; ++t)
+                for (int j : order) {
+                    lists.push_back(K + t * n_cl + j);
+                    items_of(t, j, run_len, its);
+                }
+            cl.n_entries = (int)lists.size() - cl.list_off;
+            cl.n_items = (int64_t)its.size();
+            // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that
+            // share an L2 walk the same matrices); inside a chunk the longest items first -- the kernel hands a chunk's
+            // items out in order to whichever of the XCD's workgroups asks next: the tail of the launch is a short item.
+            double total = 0.0, acc = 0.0;
+            for (const Item &it : its) total += it.w;
+            int x = 1;
+            cl.bounds[0] = 0;
+            for (size_t i = 0; i < its.size() && x < 8; ++i) {
+                acc += its[i].w;
+                while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
+            }
+            while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
+            cl.grid = prune_grid_size((int64_t)its.size(), e->device);
+            for (int c8 = 0; c8 < 8; ++c8)
+                std::stable_sort(its.begin() + cl.bounds[c8], its.begin() + cl.bounds[c8 + 1],
+                                 [](const Item &p, const Item &q) { return p.w > q.w; });
+            for (const Item &it : its) items.push_back({it.prog, it.tile0, it.n});
+        }
+    }
+}
+
 // Decides how one evaluation's work is cut -- partial updates of a batch, clade tables, tree parts -- and, when the programs
 // that follow from it differ from those on the device, resolves, schedules and uploads them (work items, per-XCD chunks,
 // dependency records of a merged clade launch).  pidx: the (class, node) -> matrix table; M: matrices of the evaluation.
@@ -111,9 +311,6 @@ WorkSplit plan_device_work(crab_engine *e, const EvalPlan &pl, const std::vector
         int n_first = 0, first_off = 0;
         e->dev_gemm_per_pat = e->dev_leaf_per_pat = 0;
         e->dev_gemm_extra = 0;
-        struct ItemRef {
-            int32_t prog, tile0, n;
-        };
         std::vector<ItemRef> items;                 // clade launches: (program, first tile, tiles) per work item
         std::vector<int32_t> dep_recs;              // merged clade launch: per program, the tables it waits for
         // CRAB_CLADE_LEVEL_LAUNCHES=1: one launch per nesting level, as in round 2.  The merged launch needs the dynamic hand-out
@@ -177,189 +374,7 @@ WorkSplit plan_device_work(crab_engine *e, const EvalPlan &pl, const std::vector
                     e->dev_gemm_per_pat += ct.main.info.n_gemm;
                     e->dev_leaf_per_pat += ct.main.info.n_leaf;
                 }
-                // Work items: runs of consecutive tiles of one (class, clade) -- a cyclic program pays its prologue (item -> header
-                // -> ops, codes -> columns -> operand image: a chain of dependent loads) once per item, later tiles start from what
-                // the previous tile's last product requested.
-                struct Item {
-                    int32_t prog, tile0, n, level;
-                    double w;
-                };
-                auto env_w = [](const char *name, double dflt) {
-                    const char *sv = std::getenv(name);
-                    return sv && sv[0] ? std::atof(sv) : dflt;
-                };
-                // predicted time of an item in products: a prologue, and per tile its products and a sixth of a product for the
-                // rest (fitted to per-workgroup busy times, scripts/gpu_prof_phases.sh with -DCRAB_CLOCK)
-                const double w_item = env_w("CRAB_W_ITEM", 0.4), w_tile = env_w("CRAB_W_TILE", 0.16);
-                const int64_t slots = prune_grid_size(int64_t(1) << 40, e->device);
-                auto items_of = [&](int t, int j, int64_t run_len, std::vector<Item> &out) {
-                    const ProgInfo &in = ct.clades[j].prog.info;
-                    const int64_t tiles = ct.clades[j].tiles;
-                    const int64_t runs = in.cyclic ? (tiles + run_len - 1) / run_len : tiles;
-                    for (int64_t r = 0; r < runs; ++r) {   // runs of equal length (+-1)
-                        const int64_t lo = tiles * r / runs, hi = tiles * (r + 1) / runs;
-                        out.push_back({(int32_t)(pl.K + t * n_cl + j), (int32_t)lo, (int32_t)(hi - lo), ct.clades[j].level,
-                                       w_item + (double)(hi - lo) * (in.n_gemm + w_tile)});
-                    }
-                };
-                int64_t run_env = 0;
-                if (const char *sv = std::getenv("CRAB_CLADE_ITEM_TILES")) run_env = std::max(1, std::min(64, std::atoi(sv)));
-                for (int t = 0; t < n_tab; ++t)
-                    for (int j = 0; j < n_cl; ++j) e->dev_gemm_extra += (int64_t)ct.clades[j].prog.info.n_gemm * ct.clades[j].tiles * prune_tile_width();
-                // A clade with more inner clades than a dependency record holds (6) cannot wait for them inside a launch.
-                bool merge = merged_clade_launch;
-                for (int j = 0; j < n_cl && merge; ++j) {
-                    int inner = 0;
-                    for (int c2 = 0; c2 < n_cl; ++c2) inner += ct.clades[c2].parent == j;
-                    merge = inner <= 6;
-                }
-                dep_recs.clear();
-                if (merge) {
-                    // ONE launch for the clade programs of all levels.  A unit = one class's copy of an outermost clade with every
-                    // clade nested inside it: tables are written and read inside a unit only.  Units are dealt to the XCDs by
-                    // predicted work (largest first, each to the XCD with the least so far), so a table and the counter that
-                    // announces it stay in one XCD's L2 -- nothing in the launch depends on coherence between XCDs.  An XCD's
-                    // items are ordered by level, then longest first; the kernel hands them out in that order and an item whose
-                    // program gathers from inner clades' tables waits for their counters (PruneArgs::deps, ::done): every item it
-                    // waits for sits earlier in the same queue, and items of level 1 wait for nothing, so by induction over the
-                    // levels every wait ends.
-                    int64_t all_tiles = 0;
-                    for (int j = 0; j < n_cl; ++j) all_tiles += ct.clades[j].tiles;
-                    const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, all_tiles * n_tab / (6 * slots)));
-                    std::vector<int> outer_of(n_cl);
-                    for (int j = 0; j < n_cl; ++j) {
-                        int r = j;
-                        while (ct.clades[r].parent >= 0) r = ct.clades[r].parent;
-                        outer_of[j] = r;
-                    }
-                    struct Unit {
-                        std::vector<Item> its;
-                        double w = 0.0;
-                    };
-                    std::vector<Unit> units;
-                    std::vector<int> unit_of(n_cl, -1);
-                    for (int t = 0; t < n_tab; ++t) {
-                        std::fill(unit_of.begin(), unit_of.end(), -1);
-                        for (int j = 0; j < n_cl; ++j) {
-                            int &u = unit_of[outer_of[j]];
-                            if (u < 0) {
-                                u = (int)units.size();
-                                units.emplace_back();
-                            }
-                            const size_t before = units[u].its.size();
-                            items_of(t, j, run_len, units[u].its);
-                            for (size_t i = before; i < units[u].its.size(); ++i) units[u].w += units[u].its[i].w;
-                        }
-                    }
-                    std::vector<int> by_w(units.size());
-                    for (size_t u = 0; u < units.size(); ++u) by_w[u] = (int)u;
-                    std::stable_sort(by_w.begin(), by_w.end(), [&](int p, int q) { return units[p].w > units[q].w; });
-                    std::vector<std::vector<Item>> of_xcd(8);
-                    double load[8] = {0};
-                    for (int u : by_w) {
-                        const int x = (int)(std::min_element(load, load + 8) - load);
-                        load[x] += units[u].w;
-                        of_xcd[x].insert(of_xcd[x].end(), units[u].its.begin(), units[u].its.end());
-                    }
-                    e->dev_clade_launches.assign(1, crab_engine::CladeLaunch{});
-                    crab_engine::CladeLaunch &cl = e->dev_clade_launches[0];
-                    cl.list_off = (int)lists.size();
-                    cl.items_off = (int64_t)items.size();
-                    for (int t = 0; t < n_tab; ++t)
-                        for (int j = 0; j < n_cl; ++j) lists.push_back(pl.K + t * n_cl + j);
-                    cl.n_entries = (int)lists.size() - cl.list_off;
-                    cl.bounds[0] = 0;
-                    for (int x = 0; x < 8; ++x) {
-                        std::stable_sort(of_xcd[x].begin(), of_xcd[x].end(),
-                                         [](const Item &p, const Item &q) { return p.level != q.level ? p.level < q.level : p.w > q.w; });
-                        for (const Item &it : of_xcd[x]) items.push_back({it.prog, it.tile0, it.n});
-                        cl.bounds[x + 1] = cl.bounds[x] + (int64_t)of_xcd[x].size();
-                    }
-                    cl.n_items = cl.bounds[8];
-                    cl.grid = prune_grid_size(cl.n_items, e->device);
-                    cl.merged = true;
-                    // one record per program: [n, program x 6, tiles needed x 6, 0, 0, 0]
-                    dep_recs.assign((size_t)n_prog * 16, 0);
-                    e->dev_clade_tiles = (int32_t)(all_tiles * n_tab);   // what the launch announces in all (PruneArgs::expect_tiles)
-                    for (int t = 0; t < n_tab; ++t)
-                        for (int j = 0; j < n_cl; ++j) {
-                            int32_t *d = dep_recs.data() + (size_t)(pl.K + t * n_cl + j) * 16;
-                            for (int c2 = 0; c2 < n_cl; ++c2)
-                                if (ct.clades[c2].parent == j) {
-                                    d[1 + d[0]] = pl.K + t * n_cl + c2;
-                                    d[7 + d[0]] = (int32_t)ct.clades[c2].tiles;
-                                    ++d[0];
-                                }
-                            if (d[0] > 0) hdrs[pl.K + t * n_cl + j].alt_codes |= 2;
-                        }
-                    // What the kernel's waits rely on, checked here rather than found out on the device: every program's items sit
-                    // in one XCD's chunk, after all items of the programs it waits for, whose tiles add up to what it waits for.
-                    {
-                        std::vector<int64_t> first(n_prog, -1), last(n_prog, -1), tiles_of(n_prog, 0);
-                        std::vector<int> xcd_of(n_prog, -1);
-                        bool ok = true;
-                        for (int x = 0; x < 8; ++x)
-                            for (int64_t i = cl.bounds[x]; i < cl.bounds[x + 1]; ++i) {
-                                const ItemRef &it = items[(size_t)(cl.items_off + i)];
-                                ok = ok && it.prog >= pl.K && it.prog < n_prog && (xcd_of[it.prog] < 0 || xcd_of[it.prog] == x);
-                                if (!ok) break;
-                                xcd_of[it.prog] = x;
-                                if (first[it.prog] < 0) first[it.prog] = i;
-                                last[it.prog] = i;
-                                tiles_of[it.prog] += it.n;
-                            }
-                        for (int pr = pl.K; pr < n_prog && ok; ++pr) {
-                            const int32_t *d = dep_recs.data() + (size_t)pr * 16;
-                            ok = first[pr] >= 0 && d[0] >= 0 && d[0] <= 6 && tiles_of[pr] == ct.clades[(pr - pl.K) % n_cl].tiles;
-                            for (int k = 0; k < d[0] && ok; ++k) {
-                                const int q = d[1 + k];
-                                ok = q >= pl.K && q < n_prog && xcd_of[q] == xcd_of[pr] && last[q] < first[pr] && tiles_of[q] == d[7 + k];
-                            }
-                        }
-                        if (!ok) fail(CRAB_ERR_STATE, "clade work items: a table would be read before it is written");
-                    }
-                } else {
-                    // one launch per level: class-major (one class's matrices stay together), clades with most products first
-                    e->dev_clade_launches.assign(ct.n_levels, crab_engine::CladeLaunch{});
-                    for (int l = 0; l < ct.n_levels; ++l) {
-                        crab_engine::CladeLaunch &cl = e->dev_clade_launches[l];
-                        cl.list_off = (int)lists.size();
-                        cl.items_off = (int64_t)items.size();
-                        std::vector<int> order;
-                        for (int j = ct.level_begin[l]; j < ct.level_begin[l + 1]; ++j) order.push_back(j);
-                        std::stable_sort(order.begin(), order.end(),
-                                         [&](int x, int y) { return ct.clades[x].prog.info.n_gemm > ct.clades[y].prog.info.n_gemm; });
-                        // runs as long as the launch can afford while it still has ~3 items per resident workgroup
-                        int64_t level_tiles = 0;
-                        for (int j : order) level_tiles += ct.clades[j].tiles;
-                        const int64_t run_len = run_env > 0 ? run_env : std::max<int64_t>(1, std::min<int64_t>(8, level_tiles * n_tab / (3 * slots)));
-                        std::vector<Item> its;
-                        for (int t = 0; t < n_tab; ++t)
-                            for (int j : order) {
-                                lists.push_back(pl.K + t * n_cl + j);
-                                items_of(t, j, run_len, its);
-                            }
-                        cl.n_entries = (int)lists.size() - cl.list_off;
-                        cl.n_items = (int64_t)its.size();
-                        // One chunk of the launch's items per XCD, of equal predicted work (class-major order: the workgroups that
-                        // share an L2 walk the same matrices); inside a chunk the longest items first -- the kernel hands a chunk's
-                        // items out in order to whichever of the XCD's workgroups asks next: the tail of the launch is a short item.
-                        double total = 0.0, acc = 0.0;
-                        for (const Item &it : its) total += it.w;
-                        int x = 1;
-                        cl.bounds[0] = 0;
-                        for (size_t i = 0; i < its.size() && x < 8; ++i) {
-                            acc += its[i].w;
-                            while (x < 8 && acc >= total * x / 8.0) cl.bounds[x++] = (int64_t)i + 1;
-                        }
-                        while (x <= 8) cl.bounds[x++] = (int64_t)its.size();
-                        cl.grid = prune_grid_size((int64_t)its.size(), e->device);
-                        for (int c8 = 0; c8 < 8; ++c8)
-                            std::stable_sort(its.begin() + cl.bounds[c8], its.begin() + cl.bounds[c8 + 1],
-                                             [](const Item &p, const Item &q) { return p.w > q.w; });
-                        for (const Item &it : its) items.push_back({it.prog, it.tile0, it.n});
-                    }
-                }
+                schedule_clade_launches(e, ct, pl.K, n_tab, n_prog, merged_clade_launch, lists, items, dep_recs, hdrs);
             }
             first_off = (int)lists.size();
             for (int b = 0; b < G; ++b) {
