@@ -882,6 +882,27 @@ __device__ __forceinline__ ProgHdr load_hdr(const ProgHdr *p)
     for (int i = 0; i < (int)(sizeof(ProgHdr) / 4); ++i) dst[i] = src[i];
     return h;
 }
+// An item record from the LDS mailbox (put there by post_next_number's DMA while the previous item ran).
+typedef int int4_lds __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ProgHdr read_hdr_lds(unsigned addr)
+{
+    int4_lds q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                 : "v"(addr)
+                 : "memory");
+    ProgHdr h;
+    int32_t *dst = reinterpret_cast<int32_t *>(&h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[i] = __builtin_amdgcn_readfirstlane(q0[i]);
+        dst[4 + i] = __builtin_amdgcn_readfirstlane(q1[i]);
+        dst[8 + i] = __builtin_amdgcn_readfirstlane(q2[i]);
+        dst[12 + i] = __builtin_amdgcn_readfirstlane(q3[i]);
+    }
+    return h;
+}
 // Byte offset, inside a gather image, of this lane's share of the column its pattern shows in alignment row `row`.
 template <int NT>
 __device__ __forceinline__ void load_code_offsets(const Walk<NT> &w, int row, unsigned (&off)[NT])
@@ -1361,13 +1382,28 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
     const bool dynamic = a.work_ctr != nullptr;
     const unsigned mbox = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)(2 * P_IMAGE * sizeof(double));
     int *const ctr = uniform_ptr(a.work_ctr + xcd);
-    auto post_next_number = [&](unsigned slot_addr) {
-        if (threadIdx.x == 0) {
-            int number;
-            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %4, %0\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(number)
-                         : "v"(0), "v"(1), "s"(ctr), "v"(slot_addr)
-                         : "memory");
+    // (with an item list the item's 64-byte record follows its number into the mailbox by LDS-DMA -- four lanes, 16 bytes each --
+    // so that the next item opens with an LDS read instead of a scalar load from memory: one round trip less on every item's
+    // critical path.  `rec`: 0 / 1, the mailbox half.)
+#ifdef CRAB_NO_RECORD_PREFETCH   // (A/B timing)
+    const bool records = false;
+#else
+    const bool records = dynamic && a.items != nullptr;
+#endif
+    auto post_next_number = [&](int half) {
+        if (wave == 0) {
+            int number = -1;
+            if (lane == 0)
+                asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %4, %0\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(number)
+                             : "v"(0), "v"(1), "s"(ctr), "v"(mbox + 4u * (unsigned)half)
+                             : "memory");
+            if (records) {
+                const int n0 = __builtin_amdgcn_readfirstlane(number);
+                if (n0 >= 0 && n0 < chunk_hi - chunk_lo && lane < 4)
+                    __builtin_amdgcn_global_load_lds(GLOBAL_PTR((const char *)(a.items + chunk_lo + n0) + lane * 16),
+                                                     LDS_PTR(smem + 2 * P_IMAGE * sizeof(double) + 64 + 64 * half), 16, 0, 0);
+            }
         }
     };
     auto read_number = [&](unsigned slot_addr) {
@@ -1390,7 +1426,8 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
         if (broken && a.host_flag && threadIdx.x == 0) __builtin_nontemporal_store(1, a.host_flag);
     }
     int announced = 0;   // tiles this workgroup has announced (merged clade launch): added to its XCD's total at the end
-    if (dynamic) post_next_number(mbox);
+    if (dynamic) post_next_number(0);
+    if (records && wave == 0) r_wait_vm0();   // (the first record: in the mailbox before the barrier below)
     long long taken = 0;   // (an exit every wave reaches whatever the mailbox holds: never more items than the chunk has)
     long long wi = chunk_lo + xj - per_xcd;
     for (int par = 0;; par ^= 1) {
@@ -1408,8 +1445,8 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             ProgHdr h;
         } item;
         int item_tiles = 1;
-        if (a.items) {   // one scalar load: the program's header, the tile and the number of tiles
-            item.h = load_hdr(a.items + wi);
+        if (a.items) {   // the program's header, the tile and the number of tiles: from the mailbox, or one scalar load
+            item.h = records ? read_hdr_lds(mbox + 64u + 64u * (unsigned)par) : load_hdr(a.items + wi);
             item.cls = item.h.prog, item.tile = item.h.tile0;
             item_tiles = __builtin_amdgcn_readfirstlane(item.h.item_tiles);   // (provably wave-uniform: it bounds the tile loop)
         } else {
@@ -1501,7 +1538,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             }
         }
 
-        if (dynamic) post_next_number(mbox + 4 * (par ^ 1));
+        if (dynamic) post_next_number(par ^ 1);
         const size_t out_row = (size_t)cls * a.n_pat_pad;
         PROF_T(0)
         // The two tiles swap roles at every product.  A later tile of the item starts in the orientation its predecessor ended
@@ -1527,7 +1564,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) e0[nt] = e1[nt] = 0;
             if (w.n_ops > 64) w.batch = w.ops[lane];
-            const ProgHdr h2 = load_hdr(a.items + wi);
+            const ProgHdr h2 = load_hdr(a.items + wi);   // (scalar cache: the item's own record was read into it or lies in L2)
             if (h2.second_leaf_mat != -1)
                 refill_codes2<NT>(w, h2.third_leaf_row, h2.fourth_leaf_row);
             else
@@ -1555,6 +1592,7 @@ __device__ __forceinline__ void prune_body(const PruneArgs &a, long long n_tiles
             }
         }
     item_done:;
+        if (records && wave == 0) r_wait_vm0();   // the next item's record has landed in the mailbox
         if (a.deps) {   // a clade program's table tiles: announced once every wave has seen its stores acknowledged
             r_wait_vm0();
             __syncthreads();
@@ -1623,7 +1661,7 @@ static int chosen_nt()
     }();
     return nt;
 }
-static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double) + 64; }   // two operand images + the item mailbox
+static size_t prune_lds_bytes() { return (size_t)2 * P_IMAGE * sizeof(double) + 256; }   // two operand images + the item mailbox (two numbers, two 64-byte records)
 // Resident workgroups per CU (every gfx950 device gives the same answer: the kernel's registers and LDS decide).  First asked
 // by prune_configure_device, on the thread that creates the engine and with its device current.
 static int blocks_per_cu()
