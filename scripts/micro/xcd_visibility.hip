@@ -66,11 +66,17 @@ __global__ void ping_pong(int *data, int *flag, int *ack, int *stale, int *xcc, 
 }
 
 template <int ST, int LD>
-void run(const char *what)
+void run(const char *what, unsigned data_flags = 0)   // data_flags: hipExtMallocWithFlags flags for the data buffer (0: hipMalloc)
 {
     const int pairs = 64;
     int *data, *flag, *ack, *stale, *xcc, *gave_up;
-    hipMalloc(&data, sizeof(int) * pairs * WORDS);
+    if (data_flags) {
+        if (hipExtMallocWithFlags((void **)&data, sizeof(int) * pairs * WORDS, data_flags) != hipSuccess) {
+            printf("%-58s: allocation with flags %#x failed\n", what, data_flags);
+            return;
+        }
+    } else
+        hipMalloc(&data, sizeof(int) * pairs * WORDS);
     hipMalloc(&flag, sizeof(int) * pairs);
     hipMalloc(&ack, sizeof(int) * pairs);
     hipMalloc(&stale, sizeof(int) * pairs);
@@ -108,5 +114,7 @@ int main()
     run<3, 3>("plain stores + L2 write-back, L2 invalidate + plain loads");
     run<1, 3>("sc1 stores, L2 invalidate + plain loads");
     run<0, 3>("plain stores, L2 invalidate + plain loads");
+    run<0, 0>("plain stores, plain loads, data in UNCACHED memory", hipDeviceMallocUncached);
+    run<0, 0>("plain stores, plain loads, data in FINE-GRAINED memory", hipDeviceMallocFinegrained);
     return 0;
 }
